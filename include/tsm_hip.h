@@ -1,0 +1,142 @@
+/*
+ * tsm_hip.h -- C ABI of libtsm_hip.so: TSM-ResNet50 clip inference on MI355X (gfx950).
+ *
+ * The reference (iucario/WorkoutDetector) has no FFI of its own: the hot path sits behind a
+ * Python duck type.  Each entry point below names the reference interface it replaces:
+ *
+ *   tsm_create / tsm_set_tensor / tsm_finalize
+ *       create_model(num_class, num_segments, base_model='resnet50', checkpoint, ...)
+ *       workoutdetector/models/tsm.py:422-476  (state-dict keys of TSM, tsm.py:250-262)
+ *       and onnxruntime.InferenceSession(ckpt) workoutdetector/utils/inference_count.py:620
+ *   tsm_forward
+ *       model.run(None, {input_name: float32[1,8,3,224,224]}) -> [float32[1,num_class]]
+ *       workoutdetector/utils/inference_count.py:273-275, scripts/eval_classification.py:43-44
+ *       == TSM.forward(x[B*T,3,H,W]) -> [B,num_class]   workoutdetector/models/tsm.py:409-419
+ *   tsm_forward_tap        (parity tests) activation after a named stage of TSM.forward
+ *   tsm_temporal_shift     TemporalShift.shift          workoutdetector/models/tsm.py:35-50
+ *   tsm_conv_bn_act        one conv + BatchNorm(eval) [+ residual] [+ ReLU] of the torchvision
+ *                          Bottleneck kept by TSM        workoutdetector/models/tsm.py:250-251,264-281
+ *   tsm_maxpool3x3s2       base_model.maxpool
+ *   tsm_head               avgpool -> fc -> view(-1,T,cls) -> mean(1)   tsm.py:411-419,165-174
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no torch / HIP types in signatures (hip streams travel as
+ *     void*; NULL = the engine's own stream).
+ *   - Every function returns 0 on success or a negative tsm_status; the message for the last
+ *     failure on an engine is tsm_last_error(engine) (engine == NULL: last create failure).
+ *   - An engine owns its weights and workspace on ONE device; it is NOT re-entrant: one
+ *     in-flight call per engine.  Independent engines (other devices / processes) coexist.
+ *   - Caller owns all input / output buffers.  With TSM_MEM_HOST the call copies and
+ *     synchronises before returning; with TSM_MEM_DEVICE the call only enqueues on `stream`.
+ *   - Activations inside the engine are NHWC fp32.
+ */
+#ifndef TSM_HIP_H_
+#define TSM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSM_ABI_VERSION 1
+
+typedef enum tsm_status {
+  TSM_OK = 0,
+  TSM_ERR_INVALID_ARG = -1,
+  TSM_ERR_HIP = -2,
+  TSM_ERR_NOT_FINALIZED = -3,
+  TSM_ERR_MISSING_TENSOR = -4,
+  TSM_ERR_SHAPE = -5,
+  TSM_ERR_CAPACITY = -6,
+  TSM_ERR_UNSUPPORTED = -7
+} tsm_status;
+
+typedef enum tsm_memkind { TSM_MEM_HOST = 0, TSM_MEM_DEVICE = 1 } tsm_memkind;
+
+/* Layout of the clip tensor handed to tsm_forward (T = num_segments). */
+typedef enum tsm_layout {
+  TSM_LAYOUT_NTCHW = 0, /* float32 [B,T,3,H,W]  -- the reference's ONNX input            */
+  TSM_LAYOUT_NTHWC = 1  /* float32 [B,T,H,W,3]  -- decoder-native, skips the host permute */
+} tsm_layout;
+
+typedef enum tsm_dtype { TSM_DTYPE_F32 = 0 } tsm_dtype;
+
+typedef struct tsm_config {
+  int32_t struct_size;  /* = sizeof(tsm_config), ABI guard                           */
+  int32_t num_class;    /* 12 for the RepCount 6-action x 2-state model              */
+  int32_t num_segments; /* T, 8 (16 for the stress config)                           */
+  int32_t height;       /* 224                                                       */
+  int32_t width;        /* 224                                                       */
+  int32_t shift_div;    /* 8: fold = C / shift_div                                   */
+  int32_t is_shift;     /* 1: temporal shift in front of every Bottleneck.conv1      */
+  int32_t max_clips;    /* workspace capacity in clips per tsm_forward call          */
+  int32_t device_id;    /* HIP device ordinal                                        */
+  int32_t dtype;        /* TSM_DTYPE_F32                                             */
+} tsm_config;
+
+typedef struct tsm_engine tsm_engine;
+
+int tsm_abi_version(void);
+
+/* Engine lifetime ------------------------------------------------------------------------- */
+int tsm_create(const tsm_config *cfg, tsm_engine **out);
+void tsm_destroy(tsm_engine *e);
+const char *tsm_last_error(const tsm_engine *e);
+
+/* Hand one state-dict tensor to the engine (host memory, float32, torch layout: conv OIHW,
+ * BN vectors [C], fc [num_class, 2048]).  Names are the reference's TSM.state_dict() keys, e.g.
+ * "base_model.layer1.0.conv1.net.weight" ("...conv1.weight" is accepted too).  The engine copies;
+ * the caller keeps ownership.  Unknown names return TSM_ERR_INVALID_ARG. */
+int tsm_set_tensor(tsm_engine *e, const char *name, const float *host_data, const int64_t *shape,
+                   int32_t ndim);
+/* Fold BatchNorm into the convs, pack to K-major NHWC tiles, upload, allocate the workspace. */
+int tsm_finalize(tsm_engine *e);
+
+/* Hot path ---------------------------------------------------------------------------------
+ * clips:  n_clips x T x 3 x H x W float32 in `layout`, in `memkind` memory.
+ * logits: float32 [n_clips, num_class] in the same memkind.  Raw scores (before softmax). */
+int tsm_forward(tsm_engine *e, const void *clips, int32_t memkind, int32_t layout, int32_t n_clips,
+                float *logits, void *stream);
+
+/* Same as tsm_forward but stops after `stage` and returns that activation (NHWC fp32) in
+ * `out` (capacity in floats); shape [N*T, H, W, C] written to out_shape[4].
+ * Stages: "input" (packed NHWC4), "conv1" (stem conv+bn+relu), "stem" (after maxpool),
+ * "layer{1..4}.{b}" (block output), "layer{L}.{b}.conv1|conv2" (branch intermediates). */
+int tsm_forward_tap(tsm_engine *e, const void *clips, int32_t memkind, int32_t layout,
+                    int32_t n_clips, const char *stage, float *out, int64_t out_capacity,
+                    int64_t out_shape[4], void *stream);
+
+/* Kernel time of the most recent tsm_forward on this engine, measured with HIP events on the
+ * stream the kernels ran on (ms); negative if none.  Synchronises on the stop event. */
+float tsm_last_forward_ms(tsm_engine *e);
+
+/* Per-op entry points (device pointers; used by the parity tests and as building blocks) ----- */
+
+/* NHWC temporal shift, x/y: [n_frames, hw, c]; n_frames % n_segment == 0; c % (4*fold_div)==0 */
+int tsm_temporal_shift(const float *x, float *y, int64_t n_frames, int32_t n_segment, int64_t hw,
+                       int32_t c, int32_t fold_div, void *stream);
+
+/* y = act( conv(x, w) * bn_scale + bn_bias [+ residual] ), NHWC.
+ * x [n,hi,wi,cin]; w OIHW [cout,cin,k,k] (device, raw); gamma/beta/mean/var [cout] (device);
+ * k in {1,3,7}; pad = k/2; residual (nullable) and y [n,ho,wo,cout].
+ * shift_segments > 0 applies the temporal shift (fold_div) to x on the fly (k == 1, stride 1).
+ * Packs the weights on every call: a test/debug entry point, not the fast path. */
+int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const float *beta,
+                    const float *mean, const float *var, const float *residual, float *y,
+                    int32_t n, int32_t hi, int32_t wi, int32_t cin, int32_t cout, int32_t k,
+                    int32_t stride, int32_t relu, int32_t shift_segments, int32_t fold_div,
+                    void *stream);
+
+int tsm_maxpool3x3s2(const float *x, float *y, int32_t n, int32_t hi, int32_t wi, int32_t c,
+                     void *stream);
+
+/* feat [n_clips*T, hw, c] NHWC -> logits [n_clips, num_class]; fc_w [num_class, c], fc_b. */
+int tsm_head(const float *feat, const float *fc_w, const float *fc_b, float *logits,
+             int32_t n_clips, int32_t n_segment, int32_t hw, int32_t c, int32_t num_class,
+             void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSM_HIP_H_ */

@@ -1,0 +1,163 @@
+"""torch-CPU fp32 restatement of the reference's TSM-ResNet50 eval forward.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Functional style: the network is
+a plain dict of tensors keyed like the reference's ``TSM.state_dict()``:
+
+    base_model.conv1.weight, base_model.bn1.{weight,bias,running_mean,running_var}
+    base_model.layer{1..4}.{b}.conv1.net.weight      (conv1 is wrapped by TemporalShift,
+                                                      workoutdetector/models/tsm.py:134-136)
+    base_model.layer{L}.{b}.conv{2,3}.weight, .bn{1,2,3}.*
+    base_model.layer{L}.0.downsample.0.weight, .downsample.1.*
+    fc.weight, fc.bias
+
+What each function follows in /root/reference (read as text, never imported):
+  temporal_shift      workoutdetector/models/tsm.py:35-50
+  shift placement     workoutdetector/models/tsm.py:125-137 ('blockres', n_round=1 for R50)
+  resnet50 trunk      torchvision 0.13.0 ResNet/Bottleneck (v1.5: stride on conv2, bias-free
+                      convs, BN eps 1e-5, maxpool k3 s2 p1), kept by tsm.py:250-251,264-281
+  head                workoutdetector/models/tsm.py:409-419 (+ SegmentConsensus :165-174)
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+R50_BLOCKS = (3, 4, 6, 3)
+R50_PLANES = (64, 128, 256, 512)
+EXPANSION = 4
+
+
+def temporal_shift(x: torch.Tensor, n_segment: int, fold_div: int = 8) -> torch.Tensor:
+    """Zero-padded out-of-place shift over the segment axis (tsm.py:35-50).
+
+    x: [N*T, C, H, W].  fold = C // fold_div.  Channels [0,fold) take frame t+1
+    (zero at t = T-1), [fold,2fold) take frame t-1 (zero at t = 0), the rest copy.
+    """
+    nt, c, h, w = x.shape
+    assert nt % n_segment == 0
+    v = x.reshape(nt // n_segment, n_segment, c, h, w)
+    fold = c // fold_div
+    out = torch.zeros_like(v)
+    out[:, :-1, :fold] = v[:, 1:, :fold]
+    out[:, 1:, fold:2 * fold] = v[:, :-1, fold:2 * fold]
+    out[:, :, 2 * fold:] = v[:, :, 2 * fold:]
+    return out.reshape(nt, c, h, w)
+
+
+def _bn(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str) -> torch.Tensor:
+    return F.batch_norm(x, sd[prefix + '.running_mean'], sd[prefix + '.running_var'],
+                        sd[prefix + '.weight'], sd[prefix + '.bias'], training=False, eps=BN_EPS)
+
+
+def _conv1_key(sd: Dict[str, torch.Tensor], prefix: str) -> str:
+    k = prefix + '.conv1.net.weight'
+    return k if k in sd else prefix + '.conv1.weight'
+
+
+def bottleneck(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, stride: int,
+               n_segment: int, shift_div: int, is_shift: bool = True) -> torch.Tensor:
+    """One torchvision Bottleneck with TSM's conv1 wrapped by the temporal shift."""
+    identity = x
+    h = temporal_shift(x, n_segment, shift_div) if is_shift else x
+    h = F.conv2d(h, sd[_conv1_key(sd, prefix)])
+    h = F.relu(_bn(h, sd, prefix + '.bn1'))
+    h = F.conv2d(h, sd[prefix + '.conv2.weight'], stride=stride, padding=1)
+    h = F.relu(_bn(h, sd, prefix + '.bn2'))
+    h = F.conv2d(h, sd[prefix + '.conv3.weight'])
+    h = _bn(h, sd, prefix + '.bn3')
+    if prefix + '.downsample.0.weight' in sd:
+        identity = F.conv2d(x, sd[prefix + '.downsample.0.weight'], stride=stride)
+        identity = _bn(identity, sd, prefix + '.downsample.1')
+    return F.relu(h + identity)
+
+
+def stem(x: torch.Tensor, sd: Dict[str, torch.Tensor]) -> torch.Tensor:
+    h = F.conv2d(x, sd['base_model.conv1.weight'], stride=2, padding=3)
+    h = F.relu(_bn(h, sd, 'base_model.bn1'))
+    return F.max_pool2d(h, kernel_size=3, stride=2, padding=1)
+
+
+def trunk(x: torch.Tensor, sd: Dict[str, torch.Tensor], n_segment: int, shift_div: int = 8,
+          is_shift: bool = True, taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """conv1..layer4 on [N*T,3,H,W] -> [N*T,2048,H/32,W/32]."""
+    h = stem(x, sd)
+    if taps is not None:
+        taps['stem'] = h
+    for li, nblocks in enumerate(R50_BLOCKS, start=1):
+        for b in range(nblocks):
+            stride = 2 if (b == 0 and li > 1) else 1
+            h = bottleneck(h, sd, f'base_model.layer{li}.{b}', stride, n_segment, shift_div, is_shift)
+            if taps is not None:
+                taps[f'layer{li}.{b}'] = h
+    return h
+
+
+def head(feat: torch.Tensor, sd: Dict[str, torch.Tensor], n_segment: int) -> torch.Tensor:
+    """avgpool -> (dropout: eval no-op) -> fc per frame -> mean over segments (tsm.py:411-419)."""
+    o = F.adaptive_avg_pool2d(feat, 1).flatten(1)
+    o = F.linear(o, sd['fc.weight'], sd['fc.bias'])
+    o = o.reshape(-1, n_segment, o.shape[-1])
+    return o.mean(dim=1, keepdim=True).squeeze(1)
+
+
+@torch.no_grad()
+def tsm_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, n_segment: int = 8,
+                shift_div: int = 8, is_shift: bool = True,
+                taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """x: [B*T,3,H,W] or [B,T,3,H,W] fp32 -> raw logits [B,num_class] (before_softmax=True)."""
+    if x.dim() == 5:
+        x = x.reshape((-1,) + tuple(x.shape[2:]))
+    assert x.dim() == 4 and x.shape[1] == 3 and x.shape[0] % n_segment == 0
+    x = x.to(torch.float32)
+    feat = trunk(x, sd, n_segment, shift_div, is_shift, taps)
+    out = head(feat, sd, n_segment)
+    if taps is not None:
+        taps['logits'] = out
+    return out
+
+
+def conv_bn_act(x: torch.Tensor, w: torch.Tensor, bn: Tuple[torch.Tensor, ...], stride: int,
+                padding: int, relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv -> BN(eval) -> (+residual) -> (ReLU): the per-op oracle for the HIP conv kernel.
+
+    bn = (gamma, beta, running_mean, running_var).
+    """
+    g, b, m, v = bn
+    h = F.conv2d(x, w, stride=stride, padding=padding)
+    h = F.batch_norm(h, m, v, g, b, training=False, eps=BN_EPS)
+    if residual is not None:
+        h = h + residual
+    return F.relu(h) if relu else h
+
+
+def layer_table(height: int = 224, width: int = 224) -> List[dict]:
+    """Per-frame GEMM shapes of the 53 convs + fc, used by bench/roofline checks."""
+    rows: List[dict] = []
+    h, w = (height + 6 - 7) // 2 + 1, (width + 6 - 7) // 2 + 1
+    rows.append(dict(name='conv1', cin=3, cout=64, k=7, s=2, m=h * w, macs=h * w * 64 * 147))
+    h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    cin = 64
+    for li, (nb, planes) in enumerate(zip(R50_BLOCKS, R50_PLANES), start=1):
+        for b in range(nb):
+            s = 2 if (b == 0 and li > 1) else 1
+            ho, wo = (h + 2 - 3) // s + 1, (w + 2 - 3) // s + 1
+            p = f'layer{li}.{b}'
+            rows.append(dict(name=p + '.conv1', cin=cin, cout=planes, k=1, s=1, m=h * w,
+                             macs=h * w * planes * cin))
+            rows.append(dict(name=p + '.conv2', cin=planes, cout=planes, k=3, s=s, m=ho * wo,
+                             macs=ho * wo * planes * planes * 9))
+            rows.append(dict(name=p + '.conv3', cin=planes, cout=planes * EXPANSION, k=1, s=1,
+                             m=ho * wo, macs=ho * wo * planes * EXPANSION * planes))
+            if b == 0:
+                rows.append(dict(name=p + '.downsample', cin=cin, cout=planes * EXPANSION, k=1, s=s,
+                                 m=ho * wo, macs=ho * wo * planes * EXPANSION * cin))
+            cin = planes * EXPANSION
+            h, w = ho, wo
+    return rows
+
+
+def macs_per_frame(height: int = 224, width: int = 224, num_class: int = 12) -> int:
+    return sum(r['macs'] for r in layer_table(height, width)) + 2048 * num_class

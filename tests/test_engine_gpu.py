@@ -1,0 +1,116 @@
+"""End-to-end parity of the HIP engine (through the C ABI) against the CPU oracle.
+
+Tolerance (BASELINE.json north_star): fp32 rtol 1e-3 on logits; written here as
+|hip - oracle| <= 1e-3*|oracle| + 1e-4*max|oracle|.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tsm_oracle
+from tests._util import assert_close, make_input
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engine224(hip_lib, sd0):
+    from workoutdetector_amd.engine import TsmEngine
+    eng = TsmEngine(num_class=12, num_segments=8, height=224, width=224, max_clips=4, state_dict=sd0)
+    yield eng
+    eng.close()
+
+
+def test_logits_parity_224(engine224, sd0):
+    x = make_input(100, 2, 8, 224, 224)
+    want = tsm_oracle.tsm_forward(sd0, torch.from_numpy(x)).numpy()
+    got = engine224.run(None, {engine224.get_inputs()[0].name: x})[0]
+    assert got.shape == (2, 12) and got.dtype == np.float32
+    assert_close(got, want, rtol=1e-3, atol_scale=1e-4, what='logits 224')
+
+
+def test_stage_taps_224(engine224, sd0):
+    """Every stage of TSM.forward, so a wrong sub-stage cannot hide behind the final tolerance."""
+    x = make_input(7, 1, 8, 224, 224)
+    taps = {}
+    tsm_oracle.tsm_forward(sd0, torch.from_numpy(x), taps=taps)
+    for stage in ['stem', 'layer1.0', 'layer1.2', 'layer2.0', 'layer2.3', 'layer3.0', 'layer3.5', 'layer4.0',
+                  'layer4.2']:
+        got = engine224.forward_tap(x, stage)
+        want = taps[stage].permute(0, 2, 3, 1).numpy()
+        assert_close(got, want, rtol=1e-3, atol_scale=1e-4, what=stage)
+
+
+def test_golden_logits(hip_lib, golden_dir):
+    """Committed oracle logits (tests/golden/tsm_r50_logits.json): all shapes incl. T=16 and non-square."""
+    from workoutdetector_amd.engine import TsmEngine
+    from workoutdetector_amd.weights import make_state_dict
+    gold = json.load(open(f'{golden_dir}/tsm_r50_logits.json'))
+    for name, case in gold.items():
+        b, t, _, h, w = case['shape']
+        eng = TsmEngine(num_class=12, num_segments=t, height=h, width=w, max_clips=b,
+                        state_dict=make_state_dict(case['weight_seed'], 12))
+        x = make_input(case['input_seed'], b, t, h, w)
+        got = eng.run(None, {'input': x})[0]
+        assert_close(got, np.array(case['logits'], dtype=np.float32), rtol=1e-3, atol_scale=1e-4, what=name)
+        eng.close()
+
+
+def test_module_duck_type_and_device_path(engine224, sd0):
+    """nn.Module style call with [B*T,3,H,W]; host, device and NTHWC inputs agree bit-for-bit."""
+    from workoutdetector_amd import _lib
+    x = make_input(3, 3, 8, 224, 224)
+    host = engine224(torch.from_numpy(x).reshape(24, 3, 224, 224))
+    assert isinstance(host, torch.Tensor) and tuple(host.shape) == (3, 12)
+    dev = engine224(torch.from_numpy(x).cuda().reshape(24, 3, 224, 224))
+    assert dev.is_cuda
+    assert torch.equal(dev.cpu(), host)
+    nthwc = np.ascontiguousarray(x.transpose(0, 1, 3, 4, 2))
+    assert np.array_equal(engine224.forward_host(nthwc, layout=_lib.LAYOUT_NTHWC), host.numpy())
+
+
+def test_batch_chunking_and_independence(engine224):
+    """B > max_clips is chunked; a clip's logits do not depend on its batch neighbours (the temporal
+    shift never crosses a clip boundary)."""
+    x = make_input(11, 6, 8, 224, 224)
+    full = engine224.run(None, {'input': x})[0]
+    for i in (0, 3, 5):
+        single = engine224.run(None, {'input': x[i:i + 1]})[0]
+        assert np.array_equal(single[0], full[i])
+
+
+def test_no_shift_engine(hip_lib, sd0):
+    from workoutdetector_amd.engine import TsmEngine
+    eng = TsmEngine(num_class=12, num_segments=8, height=64, width=64, max_clips=2, is_shift=False, state_dict=sd0)
+    x = make_input(5, 2, 8, 64, 64)
+    want = tsm_oracle.tsm_forward(sd0, torch.from_numpy(x), is_shift=False).numpy()
+    assert_close(eng.run(None, {'input': x})[0], want, rtol=1e-3, atol_scale=1e-4, what='no-shift')
+    eng.close()
+
+
+def test_error_behaviour(hip_lib, sd0, engine224):
+    from workoutdetector_amd._lib import TsmError
+    from workoutdetector_amd.engine import TsmEngine
+    with pytest.raises(ValueError):
+        engine224.run(None, {'input': np.zeros((1, 8, 3, 200, 224), np.float32)})
+    with pytest.raises(ValueError):
+        engine224.run(None, {'wrong': np.zeros((1, 8, 3, 224, 224), np.float32)})
+    eng = TsmEngine(max_clips=1)
+    with pytest.raises(TsmError) as ei:
+        eng.forward_host(np.zeros((1, 8, 3, 224, 224), np.float32))
+    assert ei.value.status == -3
+    bad = dict(sd0)
+    del bad['base_model.layer3.2.conv2.weight']
+    with pytest.raises(TsmError) as ei:
+        eng.load_state_dict(bad)
+    assert ei.value.status == -4 and 'layer3.2.conv2' in str(ei.value)
+    eng.close()
+    eng = TsmEngine(max_clips=1)
+    bad = dict(sd0)
+    bad['fc.weight'] = torch.zeros(5, 2048)
+    with pytest.raises(TsmError) as ei:
+        eng.load_state_dict(bad)
+    assert ei.value.status == -5
+    eng.close()

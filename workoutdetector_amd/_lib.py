@@ -1,0 +1,85 @@
+"""ctypes binding of libtsm_hip.so (include/tsm_hip.h).  Fails loudly when the library is missing:
+there is no CPU fallback for the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from .build import LIB_PATH
+
+ABI_VERSION = 1
+
+MEM_HOST, MEM_DEVICE = 0, 1
+LAYOUT_NTCHW, LAYOUT_NTHWC = 0, 1
+DTYPE_F32 = 0
+
+STATUS_NAMES = {0: 'TSM_OK', -1: 'TSM_ERR_INVALID_ARG', -2: 'TSM_ERR_HIP', -3: 'TSM_ERR_NOT_FINALIZED',
+                -4: 'TSM_ERR_MISSING_TENSOR', -5: 'TSM_ERR_SHAPE', -6: 'TSM_ERR_CAPACITY',
+                -7: 'TSM_ERR_UNSUPPORTED'}
+
+
+class TsmConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('struct_size', 'num_class', 'num_segments', 'height', 'width',
+                                         'shift_div', 'is_shift', 'max_clips', 'device_id', 'dtype')]
+
+
+class TsmError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f'{STATUS_NAMES.get(status, status)}: {message}')
+        self.status = status
+
+
+EXPORTS = ('tsm_abi_version', 'tsm_create', 'tsm_destroy', 'tsm_last_error', 'tsm_set_tensor', 'tsm_finalize',
+           'tsm_forward', 'tsm_forward_tap', 'tsm_last_forward_ms', 'tsm_temporal_shift', 'tsm_conv_bn_act',
+           'tsm_maxpool3x3s2', 'tsm_head')
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and declare every prototype of include/tsm_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f'{LIB_PATH} is missing: build it with `python -m workoutdetector_amd.build` '
+                          '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    vp, fp, i32, i64 = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64  # float* travel as raw addresses
+    lib.tsm_abi_version.restype = C.c_int
+    lib.tsm_abi_version.argtypes = []
+    lib.tsm_create.restype = C.c_int
+    lib.tsm_create.argtypes = [C.POINTER(TsmConfig), C.POINTER(vp)]
+    lib.tsm_destroy.restype = None
+    lib.tsm_destroy.argtypes = [vp]
+    lib.tsm_last_error.restype = C.c_char_p
+    lib.tsm_last_error.argtypes = [vp]
+    lib.tsm_set_tensor.restype = C.c_int
+    lib.tsm_set_tensor.argtypes = [vp, C.c_char_p, fp, C.POINTER(i64), i32]
+    lib.tsm_finalize.restype = C.c_int
+    lib.tsm_finalize.argtypes = [vp]
+    lib.tsm_forward.restype = C.c_int
+    lib.tsm_forward.argtypes = [vp, vp, i32, i32, i32, fp, vp]
+    lib.tsm_forward_tap.restype = C.c_int
+    lib.tsm_forward_tap.argtypes = [vp, vp, i32, i32, i32, C.c_char_p, fp, i64, C.POINTER(i64), vp]
+    lib.tsm_last_forward_ms.restype = C.c_float
+    lib.tsm_last_forward_ms.argtypes = [vp]
+    lib.tsm_temporal_shift.restype = C.c_int
+    lib.tsm_temporal_shift.argtypes = [fp, fp, i64, i32, i64, i32, i32, vp]
+    lib.tsm_conv_bn_act.restype = C.c_int
+    lib.tsm_conv_bn_act.argtypes = [fp] * 8 + [i32] * 10 + [vp]
+    lib.tsm_maxpool3x3s2.restype = C.c_int
+    lib.tsm_maxpool3x3s2.argtypes = [fp, fp, i32, i32, i32, i32, vp]
+    lib.tsm_head.restype = C.c_int
+    lib.tsm_head.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, vp]
+    if lib.tsm_abi_version() != ABI_VERSION:
+        raise ImportError(f'libtsm_hip.so ABI {lib.tsm_abi_version()} != binding {ABI_VERSION}; rebuild')
+    _lib = lib
+    return lib
+
+
+def check(status: int, engine: Optional[int] = None) -> None:
+    if status != 0:
+        msg = load().tsm_last_error(engine)
+        raise TsmError(status, msg.decode() if msg else '')

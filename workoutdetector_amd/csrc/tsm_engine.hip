@@ -1,0 +1,558 @@
+// Host engine + C ABI (include/tsm_hip.h) for the TSM-ResNet50 clip forward on MI355X.
+//
+// Owns: packed weights (BatchNorm folded, K-major), an NHWC fp32 activation workspace sized for
+// max_clips, one HIP stream, two timing events.  The forward is a fixed schedule of kernel launches
+// (tsm_kernels.hip); nothing here falls back to a CPU path.
+//
+// Reference behaviour mirrored: workoutdetector/models/tsm.py:409-419 (TSM.forward), :125-137
+// (shift in front of every Bottleneck.conv1), :451-473 (state-dict naming); torchvision-0.13
+// ResNet-50 v1.5 (stride on conv2, BN eps 1e-5).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tsm_hip.h"
+#include "tsm_kernels.h"
+
+namespace {
+
+constexpr float kBnEps = 1e-5f;
+constexpr int kBlocks[4] = {3, 4, 6, 3};
+constexpr int kPlanes[4] = {64, 128, 256, 512};
+
+std::string g_create_error;
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct ConvLayer {
+  std::string wkey, bnp;
+  int cin = 0, cout = 0, k = 1, stride = 1;
+  int cp = 0;   // channel count the kernel sees (stem: 3 -> 4)
+  int kp = 0;   // padded K
+  float *d_w = nullptr, *d_b = nullptr;
+};
+
+struct Block {
+  int conv1, conv2, conv3, down;  // indices into convs, down = -1 if none
+  int stride;
+};
+
+int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Fold BN into the conv and pack OIHW -> [Cout][Kp], K = (ky, kx, c) with c padded to cp.
+void fold_and_pack(const float *w, const float *gamma, const float *beta, const float *mean,
+                   const float *var, int cout, int cin, int k, int cp, int kp, std::vector<float> *wp,
+                   std::vector<float> *bias) {
+  wp->assign((size_t)cout * kp, 0.f);
+  bias->resize(cout);
+  for (int o = 0; o < cout; ++o) {
+    const float scale = gamma[o] / std::sqrt(var[o] + kBnEps);
+    (*bias)[o] = beta[o] - mean[o] * scale;
+    float *dst = wp->data() + (size_t)o * kp;
+    for (int c = 0; c < cin; ++c)
+      for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx)
+          dst[(ky * k + kx) * cp + c] = w[(((size_t)o * cin + c) * k + ky) * k + kx] * scale;
+  }
+}
+
+}  // namespace
+
+struct tsm_engine {
+  tsm_config cfg{};
+  std::string err;
+  hipStream_t stream = nullptr;
+  bool finalized = false;
+  std::map<std::string, HostTensor> tensors;
+  std::vector<ConvLayer> convs;
+  std::vector<Block> blocks;
+  float *d_fcw = nullptr, *d_fcb = nullptr;
+  float *d_in = nullptr;      // raw clips staged from host memory
+  float *d_in4 = nullptr;     // NHWC4 packed input
+  float *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float *d_pooled = nullptr, *d_logits = nullptr;
+  size_t buf_elems = 0;
+  int h1 = 0, w1 = 0, hp = 0, wp = 0;  // stem conv / maxpool output sizes
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool have_time = false;
+  std::vector<void *> allocs;
+};
+
+namespace {
+
+int fail(tsm_engine *e, int code, const std::string &msg) {
+  if (e) e->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define TSM_HIP(e, call)                                                                        \
+  do {                                                                                          \
+    hipError_t _st = (call);                                                                    \
+    if (_st != hipSuccess)                                                                      \
+      return fail((e), TSM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_st));        \
+  } while (0)
+
+void build_topology(tsm_engine *e) {
+  e->convs.clear();
+  e->blocks.clear();
+  ConvLayer stem;
+  stem.wkey = "base_model.conv1.weight";
+  stem.bnp = "base_model.bn1";
+  stem.cin = 3; stem.cout = 64; stem.k = 7; stem.stride = 2; stem.cp = 4;
+  stem.kp = round_up(7 * 7 * 4, 32);
+  e->convs.push_back(stem);
+  int cin = 64;
+  for (int li = 0; li < 4; ++li) {
+    for (int b = 0; b < kBlocks[li]; ++b) {
+      const int planes = kPlanes[li];
+      const int stride = (b == 0 && li > 0) ? 2 : 1;
+      const std::string p = "base_model.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+      Block blk;
+      blk.stride = stride;
+      ConvLayer c1; c1.wkey = p + ".conv1.net.weight"; c1.bnp = p + ".bn1";
+      c1.cin = cin; c1.cout = planes; c1.k = 1; c1.stride = 1; c1.cp = cin; c1.kp = cin;
+      ConvLayer c2; c2.wkey = p + ".conv2.weight"; c2.bnp = p + ".bn2";
+      c2.cin = planes; c2.cout = planes; c2.k = 3; c2.stride = stride; c2.cp = planes; c2.kp = 9 * planes;
+      ConvLayer c3; c3.wkey = p + ".conv3.weight"; c3.bnp = p + ".bn3";
+      c3.cin = planes; c3.cout = planes * 4; c3.k = 1; c3.stride = 1; c3.cp = planes; c3.kp = planes;
+      blk.conv1 = (int)e->convs.size(); e->convs.push_back(c1);
+      blk.conv2 = (int)e->convs.size(); e->convs.push_back(c2);
+      blk.conv3 = (int)e->convs.size(); e->convs.push_back(c3);
+      blk.down = -1;
+      if (b == 0) {
+        ConvLayer d; d.wkey = p + ".downsample.0.weight"; d.bnp = p + ".downsample.1";
+        d.cin = cin; d.cout = planes * 4; d.k = 1; d.stride = stride; d.cp = cin; d.kp = cin;
+        blk.down = (int)e->convs.size(); e->convs.push_back(d);
+      }
+      e->blocks.push_back(blk);
+      cin = planes * 4;
+    }
+  }
+}
+
+const HostTensor *find_tensor(const tsm_engine *e, const std::string &key) {
+  auto it = e->tensors.find(key);
+  if (it != e->tensors.end()) return &it->second;
+  // TemporalShift wraps conv1 as ".conv1.net.weight"; accept the un-wrapped spelling too.
+  const std::string net = ".conv1.net.weight";
+  if (key.size() > net.size() && key.compare(key.size() - net.size(), net.size(), net) == 0) {
+    std::string alt = key.substr(0, key.size() - net.size()) + ".conv1.weight";
+    it = e->tensors.find(alt);
+    if (it != e->tensors.end()) return &it->second;
+  }
+  return nullptr;
+}
+
+bool known_name(const tsm_engine *e, const std::string &name) {
+  if (name == "fc.weight" || name == "fc.bias") return true;
+  static const char *bn_suffix[] = {".weight", ".bias", ".running_mean", ".running_var", ".num_batches_tracked"};
+  for (const ConvLayer &c : e->convs) {
+    if (name == c.wkey) return true;
+    const std::string net = ".conv1.net.weight";
+    if (c.wkey.size() > net.size() && c.wkey.compare(c.wkey.size() - net.size(), net.size(), net) == 0 &&
+        name == c.wkey.substr(0, c.wkey.size() - net.size()) + ".conv1.weight")
+      return true;
+    for (const char *s : bn_suffix)
+      if (name == c.bnp + s) return true;
+  }
+  return false;
+}
+
+int dev_alloc(tsm_engine *e, float **p, size_t elems) {
+  void *q = nullptr;
+  TSM_HIP(e, hipMalloc(&q, elems * sizeof(float)));
+  e->allocs.push_back(q);
+  *p = static_cast<float *>(q);
+  return TSM_OK;
+}
+
+tsm::ConvParams make_params(const ConvLayer &c, const float *x, const float *res, float *y, int n, int hi,
+                            int wi, bool relu, int T, int shift_div) {
+  tsm::ConvParams p{};
+  p.x = x; p.w = c.d_w; p.bias = c.d_b; p.res = res; p.y = y;
+  p.N = n; p.Hi = hi; p.Wi = wi; p.C = c.cp; p.logC4 = ilog2(c.cp / 4);
+  p.pad = c.k / 2; p.stride = c.stride;
+  p.Ho = (hi + 2 * p.pad - c.k) / c.stride + 1;
+  p.Wo = (wi + 2 * p.pad - c.k) / c.stride + 1;
+  p.Cout = c.cout; p.Kp = c.kp; p.M = n * p.Ho * p.Wo; p.relu = relu ? 1 : 0;
+  p.T = T; p.fold = T > 0 ? c.cp / shift_div : 0;
+  return p;
+}
+
+struct Tap {
+  const float *ptr = nullptr;
+  int64_t shape[4] = {0, 0, 0, 0};
+  bool hit = false;
+};
+
+// Enqueue the forward on `s`.  If `stage` is non-null, stop right after that stage and report it.
+int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, float *d_logits,
+                hipStream_t s, const char *stage, Tap *tap) {
+  const tsm_config &cfg = e->cfg;
+  const int T = cfg.num_segments, n = n_clips * T;
+  const int shiftT = cfg.is_shift ? T : 0;
+  auto want = [&](const std::string &name) { return stage && name == stage; };
+  auto hit = [&](const float *p, int64_t a, int64_t b, int64_t c, int64_t d) {
+    tap->ptr = p; tap->shape[0] = a; tap->shape[1] = b; tap->shape[2] = c; tap->shape[3] = d; tap->hit = true;
+    return TSM_OK;
+  };
+
+  TSM_HIP(e, tsm::launch_pack_input(d_clips, e->d_in4, n, cfg.height, cfg.width,
+                                    layout == TSM_LAYOUT_NTCHW ? 1 : 0, s));
+  if (want("input")) return hit(e->d_in4, n, cfg.height, cfg.width, 4);
+
+  float *cur = e->buf[0], *out = e->buf[1], *t1 = e->buf[2], *t2 = e->buf[3], *idb = e->buf[4];
+  {
+    tsm::ConvParams p = make_params(e->convs[0], e->d_in4, nullptr, t1, n, cfg.height, cfg.width, true, 0, 1);
+    TSM_HIP(e, tsm::launch_conv(p, 7, s));
+    if (want("conv1")) return hit(t1, n, e->h1, e->w1, 64);
+    TSM_HIP(e, tsm::launch_maxpool3x3s2(t1, cur, n, e->h1, e->w1, 64, s));
+    if (want("stem")) return hit(cur, n, e->hp, e->wp, 64);
+  }
+  int h = e->hp, w = e->wp;
+  int li = 0, bi = 0;
+  for (size_t k = 0; k < e->blocks.size(); ++k) {
+    const Block &blk = e->blocks[k];
+    const std::string name = "layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+    const ConvLayer &c1 = e->convs[blk.conv1], &c2 = e->convs[blk.conv2], &c3 = e->convs[blk.conv3];
+    const int ho = (h + 2 - 3) / blk.stride + 1, wo = (w + 2 - 3) / blk.stride + 1;
+    const float *identity = cur;
+    if (blk.down >= 0) {
+      tsm::ConvParams pd = make_params(e->convs[blk.down], cur, nullptr, idb, n, h, w, false, 0, 1);
+      TSM_HIP(e, tsm::launch_conv(pd, 1, s));
+      identity = idb;
+    }
+    tsm::ConvParams p1 = make_params(c1, cur, nullptr, t1, n, h, w, true, shiftT, cfg.shift_div);
+    TSM_HIP(e, tsm::launch_conv(p1, 1, s));
+    if (want(name + ".conv1")) return hit(t1, n, h, w, c1.cout);
+    tsm::ConvParams p2 = make_params(c2, t1, nullptr, t2, n, h, w, true, 0, 1);
+    TSM_HIP(e, tsm::launch_conv(p2, 3, s));
+    if (want(name + ".conv2")) return hit(t2, n, ho, wo, c2.cout);
+    tsm::ConvParams p3 = make_params(c3, t2, identity, out, n, ho, wo, true, 0, 1);
+    TSM_HIP(e, tsm::launch_conv(p3, 1, s));
+    if (want(name)) return hit(out, n, ho, wo, c3.cout);
+    std::swap(cur, out);
+    h = ho; w = wo;
+    if (++bi == kBlocks[li]) { bi = 0; ++li; }
+  }
+  if (stage) return fail(e, TSM_ERR_INVALID_ARG, std::string("unknown stage: ") + stage);
+  TSM_HIP(e, tsm::launch_head(cur, e->d_fcw, e->d_fcb, e->d_pooled, d_logits, n_clips, T, h * w, 2048,
+                              cfg.num_class, s));
+  return TSM_OK;
+}
+
+int check_forward_args(tsm_engine *e, const void *clips, int memkind, int layout, int n_clips) {
+  if (!e) return TSM_ERR_INVALID_ARG;
+  if (!e->finalized) return fail(e, TSM_ERR_NOT_FINALIZED, "tsm_finalize has not been called");
+  if (!clips) return fail(e, TSM_ERR_INVALID_ARG, "clips is NULL");
+  if (memkind != TSM_MEM_HOST && memkind != TSM_MEM_DEVICE) return fail(e, TSM_ERR_INVALID_ARG, "bad memkind");
+  if (layout != TSM_LAYOUT_NTCHW && layout != TSM_LAYOUT_NTHWC) return fail(e, TSM_ERR_INVALID_ARG, "bad layout");
+  if (n_clips <= 0) return fail(e, TSM_ERR_INVALID_ARG, "n_clips must be positive");
+  if (n_clips > e->cfg.max_clips)
+    return fail(e, TSM_ERR_CAPACITY, "n_clips " + std::to_string(n_clips) + " exceeds max_clips " +
+                                         std::to_string(e->cfg.max_clips));
+  return TSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsm_abi_version(void) { return TSM_ABI_VERSION; }
+
+const char *tsm_last_error(const tsm_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int tsm_create(const tsm_config *cfg, tsm_engine **out) {
+  if (!cfg || !out) return fail(nullptr, TSM_ERR_INVALID_ARG, "cfg/out is NULL");
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(tsm_config))
+    return fail(nullptr, TSM_ERR_INVALID_ARG, "tsm_config.struct_size mismatch (ABI)");
+  if (cfg->num_class <= 0 || cfg->num_segments <= 0 || cfg->max_clips <= 0)
+    return fail(nullptr, TSM_ERR_INVALID_ARG, "num_class, num_segments, max_clips must be positive");
+  if (cfg->height < 32 || cfg->width < 32)
+    return fail(nullptr, TSM_ERR_INVALID_ARG, "height/width must be >= 32");
+  if (cfg->shift_div <= 0 || (64 % cfg->shift_div) != 0 || (64 / cfg->shift_div) % 4 != 0)
+    return fail(nullptr, TSM_ERR_UNSUPPORTED, "shift_div must divide 64 with fold % 4 == 0 (8 or 16... )");
+  if (cfg->dtype != TSM_DTYPE_F32) return fail(nullptr, TSM_ERR_UNSUPPORTED, "only TSM_DTYPE_F32");
+  int ndev = 0;
+  hipError_t st = hipGetDeviceCount(&ndev);
+  if (st != hipSuccess || ndev <= 0)
+    return fail(nullptr, TSM_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(st));
+  if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, TSM_ERR_INVALID_ARG, "bad device_id");
+  tsm_engine *e = new tsm_engine();
+  e->cfg = *cfg;
+  build_topology(e);
+  st = hipSetDevice(cfg->device_id);
+  if (st == hipSuccess) st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (st == hipSuccess) st = hipEventCreate(&e->ev0);
+  if (st == hipSuccess) st = hipEventCreate(&e->ev1);
+  if (st != hipSuccess) {
+    g_create_error = std::string("engine init: ") + hipGetErrorString(st);
+    delete e;
+    return TSM_ERR_HIP;
+  }
+  *out = e;
+  return TSM_OK;
+}
+
+void tsm_destroy(tsm_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device_id);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (void *p : e->allocs) (void)hipFree(p);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int tsm_set_tensor(tsm_engine *e, const char *name, const float *host_data, const int64_t *shape,
+                   int32_t ndim) {
+  if (!e) return TSM_ERR_INVALID_ARG;
+  if (!name || !host_data || !shape || ndim < 1 || ndim > 4) return fail(e, TSM_ERR_INVALID_ARG, "bad tensor args");
+  if (e->finalized) return fail(e, TSM_ERR_INVALID_ARG, "engine already finalized");
+  const std::string key(name);
+  if (!known_name(e, key)) return fail(e, TSM_ERR_INVALID_ARG, "unknown tensor name: " + key);
+  HostTensor t;
+  size_t elems = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] <= 0) return fail(e, TSM_ERR_SHAPE, "non-positive dim in " + key);
+    t.shape.push_back(shape[i]);
+    elems *= (size_t)shape[i];
+  }
+  t.data.assign(host_data, host_data + elems);
+  e->tensors[key] = std::move(t);
+  return TSM_OK;
+}
+
+int tsm_finalize(tsm_engine *e) {
+  if (!e) return TSM_ERR_INVALID_ARG;
+  if (e->finalized) return TSM_OK;
+  TSM_HIP(e, hipSetDevice(e->cfg.device_id));
+  const tsm_config &cfg = e->cfg;
+  for (ConvLayer &c : e->convs) {
+    const HostTensor *w = find_tensor(e, c.wkey);
+    const HostTensor *g = find_tensor(e, c.bnp + ".weight"), *b = find_tensor(e, c.bnp + ".bias");
+    const HostTensor *m = find_tensor(e, c.bnp + ".running_mean"), *v = find_tensor(e, c.bnp + ".running_var");
+    if (!w) return fail(e, TSM_ERR_MISSING_TENSOR, "missing " + c.wkey);
+    if (!g || !b || !m || !v) return fail(e, TSM_ERR_MISSING_TENSOR, "missing BatchNorm tensors of " + c.bnp);
+    const std::vector<int64_t> want = {c.cout, c.cin, c.k, c.k};
+    if (w->shape != want) return fail(e, TSM_ERR_SHAPE, "shape mismatch for " + c.wkey);
+    for (const HostTensor *t : {g, b, m, v})
+      if (t->shape.size() != 1 || t->shape[0] != c.cout) return fail(e, TSM_ERR_SHAPE, "BN shape mismatch for " + c.bnp);
+    std::vector<float> wp, bias;
+    fold_and_pack(w->data.data(), g->data.data(), b->data.data(), m->data.data(), v->data.data(), c.cout,
+                  c.cin, c.k, c.cp, c.kp, &wp, &bias);
+    int rc = dev_alloc(e, &c.d_w, wp.size());
+    if (rc) return rc;
+    rc = dev_alloc(e, &c.d_b, bias.size());
+    if (rc) return rc;
+    TSM_HIP(e, hipMemcpy(c.d_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
+    TSM_HIP(e, hipMemcpy(c.d_b, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  const HostTensor *fw = find_tensor(e, "fc.weight"), *fb = find_tensor(e, "fc.bias");
+  if (!fw || !fb) return fail(e, TSM_ERR_MISSING_TENSOR, "missing fc.weight / fc.bias");
+  if (fw->shape != std::vector<int64_t>{cfg.num_class, 2048} || fb->shape != std::vector<int64_t>{cfg.num_class})
+    return fail(e, TSM_ERR_SHAPE, "fc shape mismatch (want [num_class, 2048])");
+  int rc = dev_alloc(e, &e->d_fcw, fw->data.size());
+  if (rc) return rc;
+  rc = dev_alloc(e, &e->d_fcb, fb->data.size());
+  if (rc) return rc;
+  TSM_HIP(e, hipMemcpy(e->d_fcw, fw->data.data(), fw->data.size() * sizeof(float), hipMemcpyHostToDevice));
+  TSM_HIP(e, hipMemcpy(e->d_fcb, fb->data.data(), fb->data.size() * sizeof(float), hipMemcpyHostToDevice));
+
+  // Workspace: the largest activation is the stem conv output (== layer1 output), per frame
+  // h1*w1*64 floats; five rotating buffers (block in/out, two branch temporaries, identity).
+  e->h1 = (cfg.height + 6 - 7) / 2 + 1;
+  e->w1 = (cfg.width + 6 - 7) / 2 + 1;
+  e->hp = (e->h1 + 2 - 3) / 2 + 1;
+  e->wp = (e->w1 + 2 - 3) / 2 + 1;
+  const size_t frames = (size_t)cfg.max_clips * cfg.num_segments;
+  size_t per_frame = (size_t)e->h1 * e->w1 * 64;
+  const size_t l1 = (size_t)e->hp * e->wp * 256;
+  if (l1 > per_frame) per_frame = l1;
+  e->buf_elems = frames * per_frame;
+  for (int i = 0; i < 5; ++i) {
+    rc = dev_alloc(e, &e->buf[i], e->buf_elems);
+    if (rc) return rc;
+  }
+  rc = dev_alloc(e, &e->d_in, frames * 3 * cfg.height * cfg.width);
+  if (rc) return rc;
+  rc = dev_alloc(e, &e->d_in4, frames * 4 * cfg.height * cfg.width);
+  if (rc) return rc;
+  rc = dev_alloc(e, &e->d_pooled, (size_t)cfg.max_clips * 2048);
+  if (rc) return rc;
+  rc = dev_alloc(e, &e->d_logits, (size_t)cfg.max_clips * cfg.num_class);
+  if (rc) return rc;
+  e->tensors.clear();  // host copies are no longer needed
+  e->finalized = true;
+  return TSM_OK;
+}
+
+int tsm_forward(tsm_engine *e, const void *clips, int32_t memkind, int32_t layout, int32_t n_clips,
+                float *logits, void *stream) {
+  int rc = check_forward_args(e, clips, memkind, layout, n_clips);
+  if (rc) return rc;
+  if (!logits) return fail(e, TSM_ERR_INVALID_ARG, "logits is NULL");
+  TSM_HIP(e, hipSetDevice(e->cfg.device_id));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : e->stream;
+  const size_t in_elems = (size_t)n_clips * e->cfg.num_segments * 3 * e->cfg.height * e->cfg.width;
+  const float *d_clips = static_cast<const float *>(clips);
+  float *d_out = logits;
+  if (memkind == TSM_MEM_HOST) {
+    TSM_HIP(e, hipMemcpyAsync(e->d_in, clips, in_elems * sizeof(float), hipMemcpyHostToDevice, s));
+    d_clips = e->d_in;
+    d_out = e->d_logits;
+  }
+  TSM_HIP(e, hipEventRecord(e->ev0, s));
+  rc = run_forward(e, d_clips, layout, n_clips, d_out, s, nullptr, nullptr);
+  if (rc) return rc;
+  TSM_HIP(e, hipEventRecord(e->ev1, s));
+  e->have_time = true;
+  if (memkind == TSM_MEM_HOST) {
+    TSM_HIP(e, hipMemcpyAsync(logits, e->d_logits, (size_t)n_clips * e->cfg.num_class * sizeof(float),
+                              hipMemcpyDeviceToHost, s));
+    TSM_HIP(e, hipStreamSynchronize(s));
+  }
+  return TSM_OK;
+}
+
+int tsm_forward_tap(tsm_engine *e, const void *clips, int32_t memkind, int32_t layout, int32_t n_clips,
+                    const char *stage, float *out, int64_t out_capacity, int64_t out_shape[4],
+                    void *stream) {
+  int rc = check_forward_args(e, clips, memkind, layout, n_clips);
+  if (rc) return rc;
+  if (!stage || !out || !out_shape) return fail(e, TSM_ERR_INVALID_ARG, "stage/out/out_shape is NULL");
+  TSM_HIP(e, hipSetDevice(e->cfg.device_id));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : e->stream;
+  const size_t in_elems = (size_t)n_clips * e->cfg.num_segments * 3 * e->cfg.height * e->cfg.width;
+  const float *d_clips = static_cast<const float *>(clips);
+  if (memkind == TSM_MEM_HOST) {
+    TSM_HIP(e, hipMemcpyAsync(e->d_in, clips, in_elems * sizeof(float), hipMemcpyHostToDevice, s));
+    d_clips = e->d_in;
+  }
+  Tap tap;
+  rc = run_forward(e, d_clips, layout, n_clips, e->d_logits, s, stage, &tap);
+  if (rc) return rc;
+  const int64_t elems = tap.shape[0] * tap.shape[1] * tap.shape[2] * tap.shape[3];
+  for (int i = 0; i < 4; ++i) out_shape[i] = tap.shape[i];
+  if (elems > out_capacity) return fail(e, TSM_ERR_CAPACITY, "tap output buffer too small");
+  TSM_HIP(e, hipMemcpyAsync(out, tap.ptr, (size_t)elems * sizeof(float),
+                            memkind == TSM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+  TSM_HIP(e, hipStreamSynchronize(s));
+  return TSM_OK;
+}
+
+float tsm_last_forward_ms(tsm_engine *e) {
+  if (!e || !e->have_time) return -1.f;
+  if (hipEventSynchronize(e->ev1) != hipSuccess) return -1.f;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, e->ev0, e->ev1) != hipSuccess) return -1.f;
+  return ms;
+}
+
+// ---- per-op entry points (device pointers) ----------------------------------------------------
+
+int tsm_temporal_shift(const float *x, float *y, int64_t n_frames, int32_t n_segment, int64_t hw, int32_t c,
+                       int32_t fold_div, void *stream) {
+  if (!x || !y || n_frames <= 0 || hw <= 0 || c <= 0 || fold_div <= 0) return TSM_ERR_INVALID_ARG;
+  const int fold = c / fold_div;
+  hipError_t st = tsm::launch_temporal_shift(x, y, n_frames, n_segment, hw, c, fold, static_cast<hipStream_t>(stream));
+  if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,
+                                    std::string("temporal_shift: ") + hipGetErrorString(st));
+  return TSM_OK;
+}
+
+int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const float *beta, const float *mean,
+                    const float *var, const float *residual, float *y, int32_t n, int32_t hi, int32_t wi,
+                    int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t relu, int32_t shift_segments,
+                    int32_t fold_div, void *stream) {
+  if (!x || !w || !gamma || !beta || !mean || !var || !y) return fail(nullptr, TSM_ERR_INVALID_ARG, "NULL pointer");
+  if (k != 1 && k != 3 && k != 7) return fail(nullptr, TSM_ERR_UNSUPPORTED, "k must be 1, 3 or 7");
+  if (stride != 1 && stride != 2) return fail(nullptr, TSM_ERR_UNSUPPORTED, "stride must be 1 or 2");
+  const bool stem = (k == 7);
+  if (stem ? (cin != 3) : (cin % 32 != 0 || (cin & (cin - 1)) != 0))
+    return fail(nullptr, TSM_ERR_UNSUPPORTED, "cin must be 3 (k=7) or a power of two >= 32");
+  if (cout % 64 != 0) return fail(nullptr, TSM_ERR_UNSUPPORTED, "cout must be a multiple of 64");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ConvLayer c;
+  c.cin = cin; c.cout = cout; c.k = k; c.stride = stride;
+  c.cp = stem ? 4 : cin;
+  c.kp = round_up(k * k * c.cp, 32);
+  std::vector<float> hw_((size_t)cout * cin * k * k), hg(cout), hb(cout), hm(cout), hv(cout), wp, bias;
+#define TSM_HIP0(call)                                                                              \
+  do {                                                                                              \
+    hipError_t _st = (call);                                                                        \
+    if (_st != hipSuccess) return fail(nullptr, TSM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_st)); \
+  } while (0)
+  TSM_HIP0(hipStreamSynchronize(s));
+  TSM_HIP0(hipMemcpy(hw_.data(), w, hw_.size() * sizeof(float), hipMemcpyDeviceToHost));
+  TSM_HIP0(hipMemcpy(hg.data(), gamma, cout * sizeof(float), hipMemcpyDeviceToHost));
+  TSM_HIP0(hipMemcpy(hb.data(), beta, cout * sizeof(float), hipMemcpyDeviceToHost));
+  TSM_HIP0(hipMemcpy(hm.data(), mean, cout * sizeof(float), hipMemcpyDeviceToHost));
+  TSM_HIP0(hipMemcpy(hv.data(), var, cout * sizeof(float), hipMemcpyDeviceToHost));
+  fold_and_pack(hw_.data(), hg.data(), hb.data(), hm.data(), hv.data(), cout, cin, k, c.cp, c.kp, &wp, &bias);
+  float *d_w = nullptr, *d_b = nullptr, *d_x4 = nullptr;
+  TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_w), wp.size() * sizeof(float)));
+  TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_b), bias.size() * sizeof(float)));
+  TSM_HIP0(hipMemcpy(d_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
+  TSM_HIP0(hipMemcpy(d_b, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  c.d_w = d_w; c.d_b = d_b;
+  const float *xin = x;
+  if (stem) {  // NHWC3 -> NHWC4
+    TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_x4), (size_t)n * hi * wi * 4 * sizeof(float)));
+    TSM_HIP0(tsm::launch_pack_input(x, d_x4, n, hi, wi, 0, s));
+    xin = d_x4;
+  }
+  tsm::ConvParams p = make_params(c, xin, residual, y, n, hi, wi, relu != 0, shift_segments, fold_div > 0 ? fold_div : 1);
+  hipError_t st = tsm::launch_conv(p, k, s);
+  hipError_t st2 = hipStreamSynchronize(s);
+  (void)hipFree(d_w);
+  (void)hipFree(d_b);
+  if (d_x4) (void)hipFree(d_x4);
+  if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,
+                                    std::string("launch_conv: ") + hipGetErrorString(st));
+  if (st2 != hipSuccess) return fail(nullptr, TSM_ERR_HIP, std::string("conv sync: ") + hipGetErrorString(st2));
+  return TSM_OK;
+#undef TSM_HIP0
+}
+
+int tsm_maxpool3x3s2(const float *x, float *y, int32_t n, int32_t hi, int32_t wi, int32_t c, void *stream) {
+  if (!x || !y || n <= 0 || hi <= 0 || wi <= 0) return TSM_ERR_INVALID_ARG;
+  hipError_t st = tsm::launch_maxpool3x3s2(x, y, n, hi, wi, c, static_cast<hipStream_t>(stream));
+  if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,
+                                    std::string("maxpool: ") + hipGetErrorString(st));
+  return TSM_OK;
+}
+
+int tsm_head(const float *feat, const float *fc_w, const float *fc_b, float *logits, int32_t n_clips,
+             int32_t n_segment, int32_t hw, int32_t c, int32_t num_class, void *stream) {
+  if (!feat || !fc_w || !fc_b || !logits || n_clips <= 0 || n_segment <= 0 || hw <= 0 || c <= 0 || num_class <= 0)
+    return TSM_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float *pooled = nullptr;
+  hipError_t st = hipMalloc(reinterpret_cast<void **>(&pooled), (size_t)n_clips * c * sizeof(float));
+  if (st != hipSuccess) return fail(nullptr, TSM_ERR_HIP, std::string("head scratch: ") + hipGetErrorString(st));
+  st = tsm::launch_head(feat, fc_w, fc_b, pooled, logits, n_clips, n_segment, hw, c, num_class, s);
+  hipError_t st2 = hipStreamSynchronize(s);
+  (void)hipFree(pooled);
+  if (st != hipSuccess || st2 != hipSuccess)
+    return fail(nullptr, TSM_ERR_HIP, std::string("head: ") + hipGetErrorString(st != hipSuccess ? st : st2));
+  return TSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// Internal launch API shared by tsm_kernels.hip (device code) and tsm_engine.hip (host engine).
+// gfx950 only.  All activations NHWC fp32; weights packed [Cout][Kp] with K = (ky, kx, c).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tsm {
+
+struct ConvParams {
+  const float *x;     // [N, Hi, Wi, C]   C = 4 (stem, padded) or a multiple of 32
+  const float *w;     // [Cout][Kp]       BN scale folded in, zero padded to Kp
+  const float *bias;  // [Cout]           folded BN bias
+  const float *res;   // nullable [M, Cout] residual added before the activation
+  float *y;           // [M, Cout]
+  int N, Hi, Wi, C, logC4;  // (C / 4) == 1 << logC4
+  int Ho, Wo, Cout;
+  int stride, pad;
+  int Kp;    // padded K, multiple of 32
+  int M;     // N * Ho * Wo
+  int relu;
+  int T;     // > 0: temporal shift over T segments fused into the A loader (1x1, stride 1)
+  int fold;  // C / shift_div
+  int ntm, ntn;
+};
+
+// ks in {1, 3, 7}.  Returns hipSuccess or the launch error.
+hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s);
+// Tile rows the heuristics would pick (exposed for tests / DESIGN notes).
+void conv_tile_shape(const ConvParams &p, int *bm, int *bn);
+
+hipError_t launch_pack_input(const float *src, float *dst4, int64_t n_frames, int h, int w,
+                             int nchw, hipStream_t s);
+hipError_t launch_maxpool3x3s2(const float *x, float *y, int n, int hi, int wi, int c,
+                               hipStream_t s);
+hipError_t launch_temporal_shift(const float *x, float *y, int64_t n_frames, int n_segment,
+                                 int64_t hw, int c, int fold, hipStream_t s);
+// pooled: scratch [n_clips, c]
+hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, float *pooled,
+                       float *logits, int n_clips, int n_segment, int hw, int c, int num_class,
+                       hipStream_t s);
+
+}  // namespace tsm

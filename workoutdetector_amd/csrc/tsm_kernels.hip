@@ -1,0 +1,394 @@
+// Hand-written CDNA4 (gfx950) kernels for the TSM-ResNet50 clip forward.
+//
+//   conv_igemm_f32   implicit-GEMM convolution (1x1 / 3x3 / 7x7, stride 1|2) on the exact-fp32 MFMA
+//                    (v_mfma_f32_32x32x2_f32), NHWC activations, LDS-staged A (im2col rows built on
+//                    the fly, temporal shift fused into the loader) and B (packed weights),
+//                    epilogue = folded-BN bias + residual + ReLU.
+//   pack_input       [N,3,H,W] or [N,H,W,3] -> NHWC4 (zero 4th channel) so every stem tap is one 16-B load
+//   maxpool3x3s2     NHWC
+//   temporal_shift   stand-alone NHWC shift (tests; the forward uses the fused loader)
+//   head             global avg-pool + FC + mean over segments
+//
+// Reference semantics: workoutdetector/models/tsm.py:35-50 (shift), :409-419 (forward/head);
+// torchvision-0.13 ResNet-50 v1.5 Bottleneck for the conv stack.
+#include "tsm_kernels.h"
+
+namespace tsm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS row stride in floats: 32 data + 4 pad.  With ds_read_b128 (16-lane groups, 64 banks) the 16
+// rows of a group land on 16 distinct 4-bank slots (row*36 mod 64 is a permutation of multiples
+// of 4), so fragment reads are conflict-free; ds_write_b128 of 8 consecutive lanes covers one row.
+constexpr int kLds = 36;
+constexpr int kBK = 32;
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution.  GEMM view: Y[M, Cout] = A[M, K] * W^T[K, Cout],
+//   M = N*Ho*Wo output pixels, K = KS*KS*C ordered (ky, kx, c) so that NHWC input rows are
+//   contiguous along K within one tap.  One workgroup = 256 threads = 4 waves (WGM x WGN), block
+//   tile BM x BN, K-step 32.  Each wave owns (BM/WGM) x (BN/WGN) as TM x TN MFMA tiles of 32x32.
+//
+// MFMA operand order: v_mfma_f32_32x32x2_f32 takes A[i = lane&31][k = lane>>5] and
+// B[k = lane>>5][j = lane&31].  The reduction order inside K is free as long as A and B agree, so
+// each lane fetches FOUR consecutive k (one ds_read_b128) at k = 8*kk + 4*(lane>>5) + s and step s
+// of the group multiplies element s: per 8 k, one b128 per operand tile feeds 4 MFMAs.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int KS>
+__global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
+  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int APASS = BM / 32, BPASS = BN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * kLds];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // XCD-aware bijective remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
+  // contiguous run of tiles, n fastest, so co-resident blocks re-use the same A panel from L2.
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- per-thread loader state: 8 threads per 32-float row, 32 rows per pass -------------------
+  const int chunk = tid & 7, lrow = tid >> 3;
+  int a_n[APASS], a_iy[APASS], a_ix[APASS], a_t[APASS];
+  bool a_ok[APASS];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int pp = 0; pp < APASS; ++pp) {
+    const int m = m0 + lrow + 32 * pp;
+    a_ok[pp] = m < p.M;
+    const int mm = a_ok[pp] ? m : 0;
+    const int n = mm / HoWo;
+    const int rem = mm - n * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    a_n[pp] = n;
+    a_iy[pp] = oy * p.stride - p.pad;
+    a_ix[pp] = ox * p.stride - p.pad;
+    a_t[pp] = (p.T > 0) ? (n % p.T) : 0;
+  }
+  const float *wrow = p.w + (size_t)(n0 + lrow) * p.Kp + chunk * 4;
+
+  f32x4 ra[APASS], rb[BPASS];
+  const int cmask = (1 << p.logC4) - 1;
+
+  auto gload = [&](int kt) {
+    const int kq = kt * 8 + chunk;  // 16-byte chunk index along K
+    const int tap = kq >> p.logC4;
+    const int cofs = (kq & cmask) << 2;
+    const int ky = tap / KS, kx = tap - ky * KS;
+    const bool tap_ok = tap < KS * KS;
+    int dt = 0;
+    if (KS == 1 && p.T > 0) dt = cofs < p.fold ? 1 : (cofs < 2 * p.fold ? -1 : 0);
+#pragma unroll
+    for (int pp = 0; pp < APASS; ++pp) {
+      const int iy = a_iy[pp] + ky, ix = a_ix[pp] + kx;
+      bool ok = a_ok[pp] && tap_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      int n = a_n[pp];
+      if (KS == 1 && p.T > 0) {
+        // channels [0,fold) come from frame t+1, [fold,2fold) from t-1, zero outside the clip
+        ok = ok && (dt == 1 ? a_t[pp] < p.T - 1 : (dt == -1 ? a_t[pp] > 0 : true));
+        n += dt;
+      }
+      const float *src = p.x + (((size_t)n * p.Hi + iy) * p.Wi + ix) * p.C + cofs;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4 *>(src);
+      ra[pp] = v;
+    }
+#pragma unroll
+    for (int pp = 0; pp < BPASS; ++pp)
+      rb[pp] = *reinterpret_cast<const f32x4 *>(wrow + (size_t)(32 * pp) * p.Kp + kt * kBK);
+  };
+
+  auto lstore = [&](int buf) {
+    float *As = smem + buf * (BM + BN) * kLds;
+    float *Bs = As + BM * kLds;
+#pragma unroll
+    for (int pp = 0; pp < APASS; ++pp)
+      *reinterpret_cast<f32x4 *>(As + (lrow + 32 * pp) * kLds + chunk * 4) = ra[pp];
+#pragma unroll
+    for (int pp = 0; pp < BPASS; ++pp)
+      *reinterpret_cast<f32x4 *>(Bs + (lrow + 32 * pp) * kLds + chunk * 4) = rb[pp];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto compute = [&](int buf) {
+    const float *As = smem + buf * (BM + BN) * kLds + (wm * WTM + l31) * kLds + half * 4;
+    const float *Bs = smem + buf * (BM + BN) * kLds + BM * kLds + (wn * WTN + l31) * kLds + half * 4;
+#pragma unroll
+    for (int kk = 0; kk < kBK / 8; ++kk) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(As + i * 32 * kLds + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * kLds + kk * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: register-staged double buffer, one barrier per K-step ------------------------
+  const int nk = p.Kp / kBK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);  // global loads fly under the MFMAs below
+    compute(cur);
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -------------
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + l31;
+    const float b = p.bias[n];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mbase = m0 + wm * WTM + i * 32 + 4 * half;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = mbase + (e & 3) + 8 * (e >> 2);
+        if (m < p.M) {
+          const size_t o = (size_t)m * p.Cout + n;
+          float v = acc[i][j][e] + b;
+          if (p.res) v += p.res[o];
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int KS>
+static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
+  p.ntm = (p.M + BM - 1) / BM;
+  p.ntn = p.Cout / BN;
+  const dim3 grid((unsigned)(p.ntm * p.ntn));
+  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WGM, WGN, KS>), grid, dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+void conv_tile_shape(const ConvParams &p, int *bm, int *bn) {
+  // Cout is a multiple of 64 everywhere in ResNet-50.  Prefer 128x128; fall back to smaller tiles
+  // when the grid would leave most of the 256 CUs idle (small M at batch 1).
+  int BN = (p.Cout % 128 == 0) ? 128 : 64;
+  int BM = 128;
+  const long tiles128 = (long)((p.M + 127) / 128) * (p.Cout / BN);
+  if (tiles128 < 256) {
+    BM = 64;
+    BN = 64;
+  }
+  *bm = BM;
+  *bn = BN;
+}
+
+template <int KS>
+static hipError_t launch_conv_ks(const ConvParams &p, hipStream_t s) {
+  int bm, bn;
+  conv_tile_shape(p, &bm, &bn);
+  if (bm == 128 && bn == 128) return launch_conv_t<128, 128, 2, 2, KS>(p, s);
+  if (bm == 128 && bn == 64) return launch_conv_t<128, 64, 2, 2, KS>(p, s);
+  return launch_conv_t<64, 64, 2, 2, KS>(p, s);
+}
+
+hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s) {
+  if (p.Cout % 64 != 0 || p.Kp % kBK != 0 || p.M <= 0) return hipErrorInvalidValue;
+  if ((1 << p.logC4) * 4 != p.C) return hipErrorInvalidValue;
+  if (p.T > 0 && (ks != 1 || p.stride != 1 || p.N % p.T != 0 || p.fold % 4 != 0)) return hipErrorInvalidValue;
+  switch (ks) {
+    case 1: return launch_conv_ks<1>(p, s);
+    case 3: return launch_conv_ks<3>(p, s);
+    case 7: return launch_conv_ks<7>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack_input: one thread per pixel; planar reads are coalesced along W, the write is one 16-B store.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_input_kernel(const float *__restrict__ src,
+                                                         float *__restrict__ dst, int64_t n_pix_total,
+                                                         int64_t hw, int nchw) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix_total; i += stride) {
+    f32x4 v;
+    if (nchw) {
+      const int64_t n = i / hw, pix = i - n * hw;
+      const float *b = src + n * 3 * hw + pix;
+      v = {b[0], b[hw], b[2 * hw], 0.f};
+    } else {
+      const float *b = src + i * 3;
+      v = {b[0], b[1], b[2], 0.f};
+    }
+    *reinterpret_cast<f32x4 *>(dst + i * 4) = v;
+  }
+}
+
+hipError_t launch_pack_input(const float *src, float *dst4, int64_t n_frames, int h, int w, int nchw,
+                             hipStream_t s) {
+  const int64_t hw = (int64_t)h * w, total = n_frames * hw;
+  const int64_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
+  hipLaunchKernelGGL(pack_input_kernel, dim3(grid), dim3(256), 0, s, src, dst4, total, hw, nchw);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// maxpool 3x3 stride 2 pad 1, NHWC; one thread per (output pixel, 4 channels).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float *__restrict__ x,
+                                                           float *__restrict__ y, int n, int hi, int wi,
+                                                           int ho, int wo, int c4) {
+  const int64_t total = (int64_t)n * ho * wo * c4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cq = (int)(i % c4);
+    int64_t pix = i / c4;
+    const int ox = (int)(pix % wo);
+    pix /= wo;
+    const int oy = (int)(pix % ho);
+    const int64_t f = pix / ho;
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if ((unsigned)iy >= (unsigned)hi) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if ((unsigned)ix >= (unsigned)wi) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((f * hi + iy) * wi + ix) * c4 + cq) * 4);
+        m[0] = fmaxf(m[0], v[0]);
+        m[1] = fmaxf(m[1], v[1]);
+        m[2] = fmaxf(m[2], v[2]);
+        m[3] = fmaxf(m[3], v[3]);
+      }
+    }
+    *reinterpret_cast<f32x4 *>(y + i * 4) = m;
+  }
+}
+
+hipError_t launch_maxpool3x3s2(const float *x, float *y, int n, int hi, int wi, int c, hipStream_t s) {
+  if (c % 4 != 0) return hipErrorInvalidValue;
+  const int ho = (hi + 2 - 3) / 2 + 1, wo = (wi + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)n * ho * wo * (c / 4);
+  const int64_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, s, x, y, n, hi, wi, ho, wo, c / 4);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone temporal shift (NHWC).  One thread per 16-B channel quad; fold % 4 == 0 so a quad
+// never straddles a fold boundary.  tsm.py:35-50.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) temporal_shift_kernel(const float *__restrict__ x,
+                                                             float *__restrict__ y, int64_t n_frames,
+                                                             int n_segment, int64_t hw, int c4, int fold4) {
+  const int64_t total = n_frames * hw * c4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t frame_quads = hw * c4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cq = (int)(i % c4);
+    const int64_t f = i / frame_quads;
+    const int t = (int)(f % n_segment);
+    int dt = cq < fold4 ? 1 : (cq < 2 * fold4 ? -1 : 0);
+    const bool ok = dt == 1 ? t < n_segment - 1 : (dt == -1 ? t > 0 : true);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ok) v = *reinterpret_cast<const f32x4 *>(x + (i + dt * frame_quads) * 4);
+    *reinterpret_cast<f32x4 *>(y + i * 4) = v;
+  }
+}
+
+hipError_t launch_temporal_shift(const float *x, float *y, int64_t n_frames, int n_segment, int64_t hw,
+                                 int c, int fold, hipStream_t s) {
+  if (c % 4 != 0 || fold % 4 != 0 || n_segment <= 0 || n_frames % n_segment != 0) return hipErrorInvalidValue;
+  const int64_t total = n_frames * hw * (c / 4);
+  const int64_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+  hipLaunchKernelGGL(temporal_shift_kernel, dim3(grid), dim3(256), 0, s, x, y, n_frames, n_segment, hw,
+                     c / 4, fold / 4);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Head.  logits[b] = fc( mean_{t,hw} feat[b,t,hw,:] ) + bias  (avg-pool, FC and the segment mean
+// are all linear, so pooling first is exact up to fp32 summation order).  tsm.py:411-419.
+//   head_pool: grid (n_clips, c/256): thread = one channel, rows streamed coalesced.
+//   head_fc  : grid n_clips: one wave per class round-robin, shuffle reduction.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) head_pool_kernel(const float *__restrict__ feat,
+                                                        float *__restrict__ pooled, int rows, int c) {
+  const int b = blockIdx.x;
+  const int ch = blockIdx.y * 256 + threadIdx.x;
+  if (ch >= c) return;
+  const float *src = feat + (size_t)b * rows * c + ch;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 4 <= rows; r += 4) {
+    s0 += src[(size_t)(r + 0) * c];
+    s1 += src[(size_t)(r + 1) * c];
+    s2 += src[(size_t)(r + 2) * c];
+    s3 += src[(size_t)(r + 3) * c];
+  }
+  for (; r < rows; ++r) s0 += src[(size_t)r * c];
+  pooled[(size_t)b * c + ch] = ((s0 + s1) + (s2 + s3)) / (float)rows;
+}
+
+__global__ void __launch_bounds__(256) head_fc_kernel(const float *__restrict__ pooled,
+                                                      const float *__restrict__ fc_w,
+                                                      const float *__restrict__ fc_b,
+                                                      float *__restrict__ logits, int c, int num_class) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *pv = pooled + (size_t)b * c;
+  for (int cls = wave; cls < num_class; cls += 4) {
+    const float *wv = fc_w + (size_t)cls * c;
+    float s = 0.f;
+    for (int k = lane; k < c; k += 64) s += pv[k] * wv[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) logits[(size_t)b * num_class + cls] = s + fc_b[cls];
+  }
+}
+
+hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, float *pooled,
+                       float *logits, int n_clips, int n_segment, int hw, int c, int num_class,
+                       hipStream_t s) {
+  if (n_clips <= 0 || c <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(head_pool_kernel, dim3(n_clips, (c + 255) / 256), dim3(256), 0, s, feat, pooled,
+                     n_segment * hw, c);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(head_fc_kernel, dim3(n_clips), dim3(256), 0, s, pooled, fc_w, fc_b, logits, c,
+                     num_class);
+  return hipGetLastError();
+}
+
+}  // namespace tsm

@@ -1,0 +1,66 @@
+"""Multi-GPU sharding of the clip stream: one process per GPU, clips are the independent unit.
+
+The reference's inference path is a single-process batch-1 loop (utils/inference_count.py:411-416)
+with no collective.  Clips never interact (the temporal shift stays inside a clip), so clip ``j`` of
+a job goes to rank ``j // ceil(n / W)`` (contiguous blocks keep order), every rank runs its own
+engine with replicated weights, and the only exchange is ONE all-gather of per-clip logits
+``float32[ceil(n/W), num_class]`` before the serial, host-side rep counter.
+The payload is a few KB, so the step is latency-bound; xGMI bandwidth is irrelevant here.
+
+Backend: ``nccl`` (= RCCL over xGMI on ROCm) for CUDA tensors, ``gloo`` for the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world_info() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def per_rank(n_items: int, world: int) -> int:
+    return (n_items + world - 1) // world
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """[lo, hi) of the contiguous block of items owned by ``rank`` (may be empty at the tail)."""
+    per = per_rank(n_items, world)
+    lo = min(rank * per, n_items)
+    return lo, min(lo + per, n_items)
+
+
+def all_gather_logits(local: torch.Tensor, group=None) -> torch.Tensor:
+    """[per, C] on every rank (same ``per`` everywhere) -> [W*per, C] in rank order, on every rank."""
+    rank, world = world_info()
+    if world == 1:
+        return local
+    local = local.contiguous()
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local, group=group)
+    return out
+
+
+def gather_clip_logits(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Ragged form: rank r holds the logits of its ``shard_range`` block (possibly fewer than
+    ``per_rank`` rows, possibly none).  Pads to ``per_rank`` rows, all-gathers once, trims to
+    ``n_total`` rows in global clip order."""
+    rank, world = world_info()
+    if world == 1:
+        return local[:n_total]
+    per = per_rank(n_total, world)
+    lo, hi = shard_range(n_total, world, rank)
+    assert local.shape[0] == hi - lo, f'rank {rank}: got {local.shape[0]} rows for block [{lo},{hi})'
+    if local.shape[0] < per:
+        pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    return all_gather_logits(local, group)[:n_total]
+
+
+def shard_list(items: List, world: int, rank: int) -> List:
+    lo, hi = shard_range(len(items), world, rank)
+    return items[lo:hi]

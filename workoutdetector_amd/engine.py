@@ -1,0 +1,282 @@
+"""TsmEngine: Python host side of the MI355X TSM-R50 clip-inference engine.
+
+Drop-in for the two duck types the reference's hot path is written against:
+
+  * onnxruntime.InferenceSession style (workoutdetector/utils/inference_count.py:265,273-275,
+    scripts/eval_classification.py:29,44):   ``model.get_inputs()[0].name`` and
+    ``model.run(None, {name: float32[B,T,3,H,W]}) -> [float32[B,num_class]]`` (any B >= 1; the
+    reference's export is fixed at B = 1).
+  * nn.Module style (tests/test_models.py:26-28):   ``model(x[B*T,3,H,W]) -> [B,num_class]``
+    with the factory ``create_model(num_class, num_segments, base_model, checkpoint, device, ...)``
+    (workoutdetector/models/tsm.py:422-476).
+
+All arithmetic happens in libtsm_hip.so (hand-written HIP for gfx950) through the C ABI in
+include/tsm_hip.h.  No CPU fallback: construction raises if the library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .weights import make_state_dict, remap_checkpoint_keys
+
+
+@dataclass
+class NodeArg:
+    """Minimal stand-in for onnxruntime.NodeArg (only what the reference reads)."""
+    name: str
+    shape: list
+    type: str = 'tensor(float)'
+
+
+def _as_f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+class TsmEngine:
+    INPUT_NAME = 'input'
+    OUTPUT_NAME = 'output'
+
+    def __init__(self, num_class: int = 12, num_segments: int = 8, height: int = 224, width: int = 224,
+                 shift_div: int = 8, is_shift: bool = True, max_clips: int = 32, device: int = 0,
+                 state_dict: Optional[Mapping[str, object]] = None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.num_class, self.num_segments = int(num_class), int(num_segments)
+        self.height, self.width = int(height), int(width)
+        self.max_clips, self.device = int(max_clips), int(device)
+        cfg = _lib.TsmConfig(C.sizeof(_lib.TsmConfig), num_class, num_segments, height, width, shift_div,
+                             1 if is_shift else 0, max_clips, device, _lib.DTYPE_F32)
+        _lib.check(self._lib.tsm_create(C.byref(cfg), C.byref(self._h)))
+        self._finalized = False
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Mapping[str, object], strict: bool = False) -> 'TsmEngine':
+        """Hand every tensor to the engine (it folds BatchNorm and packs), then finalize.
+        Non-strict like the reference's ``load_state_dict(base_dict, strict=False)`` (tsm.py:473):
+        unknown keys are skipped, ``num_batches_tracked`` is ignored; missing tensors raise."""
+        for name, value in state_dict.items():
+            if name.endswith('num_batches_tracked'):
+                continue
+            arr = _as_f32(value.detach().cpu().numpy() if hasattr(value, 'detach') else value)
+            shape = (C.c_int64 * arr.ndim)(*arr.shape)
+            rc = self._lib.tsm_set_tensor(self._h, name.encode(), arr.ctypes.data, shape, arr.ndim)
+            if rc == -1 and not strict and b'unknown tensor name' in (self._lib.tsm_last_error(self._h) or b''):
+                continue
+            _lib.check(rc, self._h)
+        _lib.check(self._lib.tsm_finalize(self._h), self._h)
+        self._finalized = True
+        return self
+
+    # ---- onnxruntime.InferenceSession duck type ---------------------------------------------------
+    def get_inputs(self) -> List[NodeArg]:
+        return [NodeArg(self.INPUT_NAME, [None, self.num_segments, 3, self.height, self.width])]
+
+    def get_outputs(self) -> List[NodeArg]:
+        return [NodeArg(self.OUTPUT_NAME, [None, self.num_class])]
+
+    def run(self, output_names: Optional[Sequence[str]], input_feed: Dict[str, np.ndarray]) -> List[np.ndarray]:
+        if output_names is not None and list(output_names) != [self.OUTPUT_NAME]:
+            raise ValueError(f'unknown outputs {output_names}; engine has [{self.OUTPUT_NAME!r}]')
+        if set(input_feed) != {self.INPUT_NAME}:
+            raise ValueError(f'feed must have exactly the key {self.INPUT_NAME!r}, got {sorted(input_feed)}')
+        x = input_feed[self.INPUT_NAME]
+        want = (self.num_segments, 3, self.height, self.width)
+        if x.ndim != 5 or tuple(x.shape[1:]) != want:
+            raise ValueError(f'input must be [B,{want[0]},3,{want[2]},{want[3]}], got {tuple(x.shape)}')
+        return [self.forward_host(_as_f32(x))]
+
+    # ---- nn.Module duck type ----------------------------------------------------------------------
+    def __call__(self, x):
+        """x: [B*T,3,H,W] (or [B,T,3,H,W]) torch tensor (cpu or on this engine's GPU) or ndarray;
+        returns logits [B,num_class] of the same kind."""
+        is_torch = hasattr(x, 'is_cuda')
+        shape = tuple(x.shape)
+        if len(shape) == 4:
+            if shape[0] % self.num_segments or shape[1:] != (3, self.height, self.width):
+                raise ValueError(f'input must be [B*{self.num_segments},3,{self.height},{self.width}], got {shape}')
+            b = shape[0] // self.num_segments
+        elif len(shape) == 5 and shape[1:] == (self.num_segments, 3, self.height, self.width):
+            b = shape[0]
+        else:
+            raise ValueError(f'bad input shape {shape}')
+        if is_torch and x.is_cuda:
+            return self.forward_device(x.reshape(b, self.num_segments, 3, self.height, self.width))
+        arr = _as_f32(x.detach().numpy() if is_torch else x)
+        out = self.forward_host(arr.reshape(b, self.num_segments, 3, self.height, self.width))
+        if is_torch:
+            import torch
+            return torch.from_numpy(out)
+        return out
+
+    def eval(self) -> 'TsmEngine':  # nn.Module API used by callers; inference-only engine
+        return self
+
+    def to(self, *_args, **_kw) -> 'TsmEngine':
+        return self
+
+    # ---- forwards ---------------------------------------------------------------------------------
+    def forward_host(self, clips: np.ndarray, layout: int = _lib.LAYOUT_NTCHW) -> np.ndarray:
+        """clips: float32 [B,T,3,H,W] (or [B,T,H,W,3] with LAYOUT_NTHWC) in host memory."""
+        self._need_finalized()
+        b = clips.shape[0]
+        out = np.empty((b, self.num_class), dtype=np.float32)
+        for s in range(0, b, self.max_clips):
+            chunk = np.ascontiguousarray(clips[s:s + self.max_clips])
+            o = out[s:s + chunk.shape[0]]
+            _lib.check(self._lib.tsm_forward(self._h, chunk.ctypes.data, _lib.MEM_HOST, layout, chunk.shape[0],
+                                             o.ctypes.data, None), self._h)
+        return out
+
+    def forward_device(self, clips, out=None, layout: int = _lib.LAYOUT_NTCHW):
+        """clips: contiguous float32 CUDA tensor [B,T,3,H,W] on this engine's device.  Enqueues on
+        torch's current stream and returns a CUDA tensor [B,num_class] (no host sync)."""
+        import torch
+        self._need_finalized()
+        if not (clips.is_cuda and clips.dtype == torch.float32):
+            raise ValueError('forward_device needs a float32 CUDA tensor')
+        if clips.device.index != self.device:
+            raise ValueError(f'tensor on cuda:{clips.device.index}, engine on cuda:{self.device}')
+        clips = clips.contiguous()
+        b = clips.shape[0]
+        if out is None:
+            out = torch.empty((b, self.num_class), dtype=torch.float32, device=clips.device)
+        stream = torch.cuda.current_stream(clips.device).cuda_stream
+        for s in range(0, b, self.max_clips):
+            n = min(self.max_clips, b - s)
+            _lib.check(self._lib.tsm_forward(self._h, clips[s:s + n].data_ptr(), _lib.MEM_DEVICE, layout, n,
+                                             out[s:s + n].data_ptr(), stream), self._h)
+        return out
+
+    def forward_tap(self, clips: np.ndarray, stage: str) -> np.ndarray:
+        """Activation after ``stage`` as NHWC float32 ndarray (parity tests)."""
+        self._need_finalized()
+        clips = _as_f32(clips)
+        n = clips.shape[0] * self.num_segments
+        cap = n * max(((self.height + 1) // 2) * ((self.width + 1) // 2) * 64, self.height * self.width * 4)
+        buf = np.empty(cap, dtype=np.float32)
+        shape = (C.c_int64 * 4)()
+        _lib.check(self._lib.tsm_forward_tap(self._h, clips.ctypes.data, _lib.MEM_HOST, _lib.LAYOUT_NTCHW,
+                                             clips.shape[0], stage.encode(), buf.ctypes.data, cap, shape, None),
+                   self._h)
+        dims = tuple(int(v) for v in shape)
+        return buf[:int(np.prod(dims))].reshape(dims).copy()
+
+    @property
+    def last_forward_ms(self) -> float:
+        return float(self._lib.tsm_last_forward_ms(self._h))
+
+    def _need_finalized(self) -> None:
+        if not self._finalized:
+            raise _lib.TsmError(-3, 'load_state_dict() has not been called')
+
+    def close(self) -> None:
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.tsm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def create_model(num_class: int = 2, num_segments: int = 8, base_model: str = 'resnet50',
+                 checkpoint: Optional[str] = None, device: Optional[object] = None, fc_lr5: bool = True,
+                 is_shift: bool = True, shift_div: int = 8, shift_place: str = 'blockres',
+                 consensus_type: str = 'avg', img_feature_dim: int = 256, non_local: bool = False,
+                 height: int = 224, width: int = 224, max_clips: int = 32, seed: int = 0,
+                 **kwargs) -> TsmEngine:
+    """Counterpart of the reference factory (tsm.py:422-476) returning a ready TsmEngine.
+
+    ``checkpoint`` is a ``torch.save``d dict with a ``state_dict`` entry; its keys are remapped like
+    the reference does (strip the first dotted component, last two entries are the classifier).
+    Without a checkpoint the reference starts from torchvision's ImageNet weights, which cannot be
+    fetched offline: the engine then gets the seeded synthetic weights of ``weights.make_state_dict``.
+    """
+    if base_model != 'resnet50':
+        raise NotImplementedError(f'{base_model}: the engine implements resnet50 only')
+    assert consensus_type in ('avg',), 'the engine implements the avg consensus'
+    assert shift_place == 'blockres', 'the engine implements blockres placement'
+    if non_local:
+        raise NotImplementedError('non_local')
+    dev = 0
+    if device is not None:
+        s = str(device)
+        if s == 'cpu':
+            raise RuntimeError('TsmEngine has no CPU path; pass a CUDA/HIP device')
+        dev = int(s.split(':')[1]) if ':' in s else 0
+    if checkpoint is not None:
+        import torch
+        ckpt = torch.load(checkpoint, map_location='cpu')
+        sd = remap_checkpoint_keys(ckpt['state_dict'], num_class)
+    else:
+        sd = make_state_dict(seed=seed, num_class=num_class)
+    return TsmEngine(num_class=num_class, num_segments=num_segments, height=height, width=width,
+                     shift_div=shift_div, is_shift=is_shift, max_clips=max_clips, device=dev, state_dict=sd)
+
+
+# ---- per-op wrappers over the C ABI (device tensors), used by tests ----------------------------------
+def _ptr(t) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t) -> int:
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def temporal_shift_nhwc(x, n_segment: int, fold_div: int = 8):
+    """x: CUDA float32 [N*T, H, W, C] (NHWC) -> shifted copy (tsm.py:35-50)."""
+    import torch
+    x = x.contiguous()
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().tsm_temporal_shift(x.data_ptr(), y.data_ptr(), n, n_segment, h * w, c, fold_div,
+                                              _stream(x)))
+    return y
+
+
+def conv_bn_act_nhwc(x, w, gamma, beta, mean, var, stride: int = 1, relu: bool = True, residual=None,
+                     shift_segments: int = 0, fold_div: int = 8):
+    """x NHWC [n,h,w,cin], w OIHW; returns NHWC [n,ho,wo,cout]."""
+    import torch
+    x = x.contiguous()
+    n, hi, wi, cin = x.shape
+    cout, _, k, _ = w.shape
+    pad = k // 2
+    ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    res = None if residual is None else residual.contiguous()
+    args = [t.contiguous() for t in (w, gamma, beta, mean, var)]
+    _lib.check(_lib.load().tsm_conv_bn_act(x.data_ptr(), *[a.data_ptr() for a in args], _ptr(res), y.data_ptr(),
+                                           n, hi, wi, cin, cout, k, stride, int(relu), shift_segments, fold_div,
+                                           _stream(x)))
+    return y
+
+
+def maxpool3x3s2_nhwc(x):
+    import torch
+    x = x.contiguous()
+    n, hi, wi, c = x.shape
+    y = torch.empty((n, (hi - 1) // 2 + 1, (wi - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().tsm_maxpool3x3s2(x.data_ptr(), y.data_ptr(), n, hi, wi, c, _stream(x)))
+    return y
+
+
+def head_nhwc(feat, fc_w, fc_b, n_segment: int):
+    import torch
+    feat = feat.contiguous()
+    n, h, w, c = feat.shape
+    b = n // n_segment
+    out = torch.empty((b, fc_w.shape[0]), dtype=torch.float32, device=feat.device)
+    _lib.check(_lib.load().tsm_head(feat.data_ptr(), fc_w.contiguous().data_ptr(), fc_b.contiguous().data_ptr(),
+                                    out.data_ptr(), b, n_segment, h * w, c, fc_w.shape[0], _stream(feat)))
+    return out

@@ -1,0 +1,96 @@
+"""Weights for the TSM-R50 engine: seeded synthetic state dicts and checkpoint key remapping.
+
+No trained weights exist offline, so benches and parity tests use
+a deterministic, numerically non-trivial state dict keyed exactly like the reference's
+``TSM.state_dict()`` (workoutdetector/models/tsm.py:250-262; conv1 of every Bottleneck is
+wrapped by TemporalShift, hence ``...conv1.net.weight``, tsm.py:134-136).
+
+``remap_checkpoint_keys`` mirrors ``create_model``'s loader (tsm.py:451-473): the last two
+entries of the checkpoint are the classifier, they become ``fc.weight/bias`` iff their row
+count equals ``num_class``; every key loses its first dotted component.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Iterable, List, Mapping, Tuple
+
+import numpy as np
+
+R50_BLOCKS = (3, 4, 6, 3)
+R50_PLANES = (64, 128, 256, 512)
+EXPANSION = 4
+
+
+def conv_specs() -> List[Tuple[str, str, int, int, int]]:
+    """(conv weight key, bn prefix, cout, cin, k) for the 53 convs of TSM-R50, in forward order."""
+    specs = [('base_model.conv1.weight', 'base_model.bn1', 64, 3, 7)]
+    cin = 64
+    for li, (nb, planes) in enumerate(zip(R50_BLOCKS, R50_PLANES), start=1):
+        for b in range(nb):
+            p = f'base_model.layer{li}.{b}'
+            specs.append((p + '.conv1.net.weight', p + '.bn1', planes, cin, 1))
+            specs.append((p + '.conv2.weight', p + '.bn2', planes, planes, 3))
+            specs.append((p + '.conv3.weight', p + '.bn3', planes * EXPANSION, planes, 1))
+            if b == 0:
+                specs.append((p + '.downsample.0.weight', p + '.downsample.1',
+                              planes * EXPANSION, cin, 1))
+            cin = planes * EXPANSION
+    return specs
+
+
+def make_state_dict(seed: int = 0, num_class: int = 12) -> 'OrderedDict[str, np.ndarray]':
+    """Deterministic fp32 state dict (numpy arrays, torch layouts: conv OIHW, fc [cls, 2048]).
+
+    He-normal convs; BN statistics are all non-trivial so the fold is exercised; the last BN of
+    each residual branch is damped so activations stay O(1) through 16 blocks; the classifier uses
+    std 0.05 (the reference's init std 0.001, tsm.py:260-262, gives logits too flat to
+    discriminate between clips).
+    """
+    rng = np.random.default_rng(seed)
+    sd: 'OrderedDict[str, np.ndarray]' = OrderedDict()
+
+    def f32(a):
+        return np.ascontiguousarray(a, dtype=np.float32)
+
+    for wkey, bnp, cout, cin, k in conv_specs():
+        fan_in = cin * k * k
+        sd[wkey] = f32(rng.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / fan_in))
+        damp = 0.35 if bnp.endswith('.bn3') else 1.0
+        sd[bnp + '.weight'] = f32(rng.uniform(0.8, 1.2, cout) * damp)
+        sd[bnp + '.bias'] = f32(rng.standard_normal(cout) * 0.1)
+        sd[bnp + '.running_mean'] = f32(rng.standard_normal(cout) * 0.1)
+        sd[bnp + '.running_var'] = f32(rng.uniform(0.6, 1.4, cout))
+    sd['fc.weight'] = f32(rng.standard_normal((num_class, 512 * EXPANSION)) * 0.05)
+    sd['fc.bias'] = f32(rng.standard_normal(num_class) * 0.1)
+    return sd
+
+
+def remap_checkpoint_keys(state_dict: Mapping[str, object], num_class: int) -> 'OrderedDict[str, object]':
+    """Checkpoint ``state_dict`` (``module.``/``model.``-prefixed) -> engine keys."""
+    keys = list(state_dict.keys())
+    fc_w, fc_b = keys[-2], keys[-1]
+    items = OrderedDict(state_dict)
+    w = items[fc_w]
+    rows = w.shape[0]
+    if rows == num_class:
+        items['module.fc.weight'] = items[fc_w]
+        items['module.fc.bias'] = items[fc_b]
+    if fc_w != 'module.fc.weight':
+        del items[fc_w]
+    if fc_b != 'module.fc.bias':
+        del items[fc_b]
+    return OrderedDict(('.'.join(k.split('.')[1:]), v) for k, v in items.items())
+
+
+def required_keys(num_class_known: bool = True) -> Iterable[str]:
+    for wkey, bnp, *_ in conv_specs():
+        yield wkey
+        for s in ('.weight', '.bias', '.running_mean', '.running_var'):
+            yield bnp + s
+    yield 'fc.weight'
+    yield 'fc.bias'
+
+
+def to_torch(sd: Mapping[str, np.ndarray]) -> Dict[str, 'object']:
+    import torch
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
