@@ -36,11 +36,27 @@ def flops_per_clip(t, h, w, num_class=12):
     return 2.0 * macs_per_frame(h, w, num_class) * t
 
 
+def host_cores():
+    """Cores this process may actually use: affinity mask and cgroup CPU quota, not the box's total."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get('TSM_BENCH_CPU_THREADS', '16')))
+
+
 def cpu_baseline(sd_np, t, h, w, budget_s=15.0):
     import torch
     from oracle import tsm_oracle
     from workoutdetector_amd.weights import to_torch
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = to_torch(sd_np)
     x = torch.randn(1, t, 3, h, w, generator=torch.Generator().manual_seed(0))

@@ -20,8 +20,10 @@
  *   tsm_head               avgpool -> fc -> view(-1,T,cls) -> mean(1)   tsm.py:411-419,165-174
  *
  * Conventions
- *   - Plain pointers and sizes only; no torch / HIP types in signatures (hip streams travel as
- *     void*; NULL = the engine's own stream).
+ *   - Plain pointers and sizes only; no torch / HIP types in signatures.  hip streams travel as
+ *     void*.  NULL means: the device's default (null) stream for TSM_MEM_DEVICE calls and per-op
+ *     entry points (so work is ordered after whatever produced the buffers there -- torch's default
+ *     stream is the null stream), the engine's private stream for TSM_MEM_HOST calls.
  *   - Every function returns 0 on success or a negative tsm_status; the message for the last
  *     failure on an engine is tsm_last_error(engine) (engine == NULL: last create failure).
  *   - An engine owns its weights and workspace on ONE device; it is NOT re-entrant: one

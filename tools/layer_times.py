@@ -1,0 +1,45 @@
+"""Per-layer time and TFLOP/s of one forward from a rocprofv3 --kernel-trace CSV.
+
+    python tools/layer_times.py gpurun_out/prof1/runc/700_kernel_trace.csv [frames]
+"""
+import csv
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.tsm_oracle import layer_table  # noqa: E402
+
+
+def main(path, frames=256):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    names = [r['Kernel_Name'] for r in rows]
+    idx = [i for i, n in enumerate(names) if 'pack_input' in n]
+    fw = rows[idx[-2]:idx[-1]]
+    convs = [r for r in fw if 'conv_' in r['Kernel_Name']]
+    byname = {r['name']: r for r in layer_table()}
+    order = ['conv1']
+    for li, nb in enumerate((3, 4, 6, 3), 1):
+        for b in range(nb):
+            p = f'layer{li}.{b}'
+            if b == 0:
+                order.append(p + '.downsample')
+            order += [p + '.conv1', p + '.conv2', p + '.conv3']
+    if len(order) != len(convs):
+        print('launch count', len(convs), 'differs from layer count', len(order))
+    tot = totf = 0.0
+    for nm, r in zip(order, convs):
+        dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        fl = 2 * byname[nm]['macs'] * frames
+        tot += dur
+        totf += fl
+        kn = r['Kernel_Name'].split('<')[1].split('>')[0] if '<' in r['Kernel_Name'] else r['Kernel_Name'][:30]
+        grid = int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))
+        print(f"{nm:22s} {kn:20s} wgs={grid:6d} {dur:8.1f}us {fl / dur / 1e6:7.1f} TF/s  vgpr={r.get('VGPR_Count','?')}")
+    span = (int(fw[-1]['End_Timestamp']) - int(fw[0]['Start_Timestamp'])) / 1e3
+    print(f'sum conv {tot:.1f} us = {totf / tot / 1e6:.1f} TF/s; forward span {span:.1f} us; '
+          f'other kernels {sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in fw if "conv_" not in r["Kernel_Name"]):.1f} us')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 256)

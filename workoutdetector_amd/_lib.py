@@ -45,6 +45,14 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f'{LIB_PATH} is missing: build it with `python -m workoutdetector_amd.build` '
                           '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    # PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP runtimes
+    # in one process cannot both own the device, so make sure torch's copy is the one already mapped
+    # when libtsm_hip.so's DT_NEEDED is resolved: import torch first (it is the plumbing for device
+    # memory and streams anyway).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, fp, i32, i64 = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64  # float* travel as raw addresses
     lib.tsm_abi_version.restype = C.c_int

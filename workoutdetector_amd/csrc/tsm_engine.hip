@@ -255,6 +255,14 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   return TSM_OK;
 }
 
+// Device-memory calls run where the caller's data lives: `stream`, NULL meaning the device's default
+// (null) stream -- which is what torch's default stream is.  Host-memory calls are synchronous and use
+// the engine's private stream unless one is given.
+hipStream_t pick_stream(tsm_engine *e, int memkind, void *stream) {
+  if (stream) return static_cast<hipStream_t>(stream);
+  return memkind == TSM_MEM_HOST ? e->stream : nullptr;
+}
+
 int check_forward_args(tsm_engine *e, const void *clips, int memkind, int layout, int n_clips) {
   if (!e) return TSM_ERR_INVALID_ARG;
   if (!e->finalized) return fail(e, TSM_ERR_NOT_FINALIZED, "tsm_finalize has not been called");
@@ -409,7 +417,7 @@ int tsm_forward(tsm_engine *e, const void *clips, int32_t memkind, int32_t layou
   if (rc) return rc;
   if (!logits) return fail(e, TSM_ERR_INVALID_ARG, "logits is NULL");
   TSM_HIP(e, hipSetDevice(e->cfg.device_id));
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : e->stream;
+  hipStream_t s = pick_stream(e, memkind, stream);
   const size_t in_elems = (size_t)n_clips * e->cfg.num_segments * 3 * e->cfg.height * e->cfg.width;
   const float *d_clips = static_cast<const float *>(clips);
   float *d_out = logits;
@@ -438,7 +446,7 @@ int tsm_forward_tap(tsm_engine *e, const void *clips, int32_t memkind, int32_t l
   if (rc) return rc;
   if (!stage || !out || !out_shape) return fail(e, TSM_ERR_INVALID_ARG, "stage/out/out_shape is NULL");
   TSM_HIP(e, hipSetDevice(e->cfg.device_id));
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : e->stream;
+  hipStream_t s = pick_stream(e, memkind, stream);
   const size_t in_elems = (size_t)n_clips * e->cfg.num_segments * 3 * e->cfg.height * e->cfg.width;
   const float *d_clips = static_cast<const float *>(clips);
   if (memkind == TSM_MEM_HOST) {

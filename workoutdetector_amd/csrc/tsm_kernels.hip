@@ -34,14 +34,32 @@ constexpr int kBK = 32;
 // B[k = lane>>5][j = lane&31].  The reduction order inside K is free as long as A and B agree, so
 // each lane fetches FOUR consecutive k (one ds_read_b128) at k = 8*kk + 4*(lane>>5) + s and step s
 // of the group multiplies element s: per 8 k, one b128 per operand tile feeds 4 MFMAs.
+//
+// Loader: branch-free.  Both operands come through raw buffer loads whose descriptor is rebased per
+// workgroup (so 32-bit byte offsets always suffice) and whose hardware range check returns zeros
+// for an offset of kInvalid: im2col padding, rows past M and the zero frames of the temporal shift
+// cost a v_cndmask on the offset instead of a branch.  Everything that depends only on the row
+// (pixel decode, padding mask, shift validity) is computed once per thread before the K loop.
+//
+// Epilogue: accumulators go through LDS once so that global traffic is 16 B per lane along Cout
+// (residual read, bias, ReLU, store), i.e. whole 128-B lines instead of 4-B scalars.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int KS>
+constexpr unsigned kInvalid = 0x80000000u;  // >= num_records of every descriptor below
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+}
+
+template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT>
 __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  static_assert(!SHIFT || KS == 1, "the temporal shift is fused into 1x1 convs only");
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int APASS = BM / 32, BPASS = BN / 32;
+  constexpr int CLD = BN + 4;  // epilogue staging row stride (floats)
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+  static_assert(BM * CLD <= 2 * (BM + BN) * kLds, "epilogue staging must fit the operand buffers");
 
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * kLds];
 
@@ -59,55 +77,99 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
   const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
   const int m0 = tm * BM, n0 = tn * BN;
 
+  // ---- descriptors, rebased to this workgroup's first input frame / first weight row ------------
+  const int HoWo = p.Ho * p.Wo;
+  const int n_first = m0 / HoWo;
+  const int frame0 = SHIFT ? (n_first > 0 ? n_first - 1 : 0) : n_first;
+  const size_t frame_elems = (size_t)p.Hi * p.Wi * p.C;
+  const size_t a_bytes = ((size_t)p.N - frame0) * frame_elems * 4;
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.x + (size_t)frame0 * frame_elems), 0,
+      (int)(a_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : a_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.w + (size_t)n0 * p.Kp), 0, BN * p.Kp * 4, 0x00020000);
+
   // ---- per-thread loader state: 8 threads per 32-float row, 32 rows per pass -------------------
   const int chunk = tid & 7, lrow = tid >> 3;
-  int a_n[APASS], a_iy[APASS], a_ix[APASS], a_t[APASS];
-  bool a_ok[APASS];
-  const int HoWo = p.Ho * p.Wo;
+  const int frame_bytes = (int)(frame_elems * 4);
+  unsigned a_off[APASS];                       // byte offset of (row, tap 0, this thread's chunk)
+  unsigned a_offp[SHIFT ? APASS : 1], a_offm[SHIFT ? APASS : 1];
+  unsigned a_mask[KS == 3 ? APASS : 1];
+  int a_iy[KS == 7 ? APASS : 1], a_ix[KS == 7 ? APASS : 1];
 #pragma unroll
   for (int pp = 0; pp < APASS; ++pp) {
     const int m = m0 + lrow + 32 * pp;
-    a_ok[pp] = m < p.M;
-    const int mm = a_ok[pp] ? m : 0;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : m0;
     const int n = mm / HoWo;
     const int rem = mm - n * HoWo;
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    a_n[pp] = n;
-    a_iy[pp] = oy * p.stride - p.pad;
-    a_ix[pp] = ox * p.stride - p.pad;
-    a_t[pp] = (p.T > 0) ? (n % p.T) : 0;
+    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+    if (KS == 7) {
+      a_off[pp] = ok ? (unsigned)((n - frame0) * frame_bytes) : kInvalid;
+      a_iy[pp] = iy0;
+      a_ix[pp] = ix0;
+    } else {
+      const int base = (n - frame0) * frame_bytes + ((iy0 * p.Wi + ix0) * p.C + chunk * 4) * 4;
+      a_off[pp] = (KS == 1 && !ok) ? kInvalid : (unsigned)base;
+      if (KS == 3) {
+        unsigned mask = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            if ((unsigned)(iy0 + ky) < (unsigned)p.Hi && (unsigned)(ix0 + kx) < (unsigned)p.Wi)
+              mask |= 1u << (ky * 3 + kx);
+        a_mask[pp] = ok ? mask : 0u;
+      }
+      if (SHIFT) {
+        const int t = n % p.T;  // channels [0,fold) <- frame t+1, [fold,2fold) <- frame t-1
+        a_offp[pp] = (ok && t < p.T - 1) ? (unsigned)(base + frame_bytes) : kInvalid;
+        a_offm[pp] = (ok && t > 0) ? (unsigned)(base - frame_bytes) : kInvalid;
+      }
+    }
   }
-  const float *wrow = p.w + (size_t)(n0 + lrow) * p.Kp + chunk * 4;
+  unsigned b_off[BPASS];
+#pragma unroll
+  for (int pp = 0; pp < BPASS; ++pp) b_off[pp] = (unsigned)(((lrow + 32 * pp) * p.Kp + chunk * 4) * 4);
 
   f32x4 ra[APASS], rb[BPASS];
-  const int cmask = (1 << p.logC4) - 1;
 
   auto gload = [&](int kt) {
-    const int kq = kt * 8 + chunk;  // 16-byte chunk index along K
-    const int tap = kq >> p.logC4;
-    const int cofs = (kq & cmask) << 2;
-    const int ky = tap / KS, kx = tap - ky * KS;
-    const bool tap_ok = tap < KS * KS;
-    int dt = 0;
-    if (KS == 1 && p.T > 0) dt = cofs < p.fold ? 1 : (cofs < 2 * p.fold ? -1 : 0);
+    const unsigned kbytes = (unsigned)kt * (kBK * 4);
+    if (KS == 1) {
+      if (SHIFT) {
+        const int c = kt * kBK + chunk * 4;
+        const bool fwd = c < p.fold, bwd = c < 2 * p.fold;
 #pragma unroll
-    for (int pp = 0; pp < APASS; ++pp) {
-      const int iy = a_iy[pp] + ky, ix = a_ix[pp] + kx;
-      bool ok = a_ok[pp] && tap_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      int n = a_n[pp];
-      if (KS == 1 && p.T > 0) {
-        // channels [0,fold) come from frame t+1, [fold,2fold) from t-1, zero outside the clip
-        ok = ok && (dt == 1 ? a_t[pp] < p.T - 1 : (dt == -1 ? a_t[pp] > 0 : true));
-        n += dt;
+        for (int pp = 0; pp < APASS; ++pp)
+          ra[pp] = buf_load4(rsrcA, fwd ? a_offp[pp] : (bwd ? a_offm[pp] : a_off[pp]), kbytes);
+      } else {
+#pragma unroll
+        for (int pp = 0; pp < APASS; ++pp) ra[pp] = buf_load4(rsrcA, a_off[pp], kbytes);
       }
-      const float *src = p.x + (((size_t)n * p.Hi + iy) * p.Wi + ix) * p.C + cofs;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4 *>(src);
-      ra[pp] = v;
+    } else if (KS == 3) {
+      // C >= 32 so a K-step never straddles a tap: tap and its offset are wave-uniform scalars
+      const int tap = (kt * kBK) >> (p.logC4 + 2);
+      const int c0 = kt * kBK - tap * p.C;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int tap_off = ((ky * p.Wi + kx) * p.C + c0) * 4;
+#pragma unroll
+      for (int pp = 0; pp < APASS; ++pp)
+        ra[pp] = buf_load4(rsrcA, ((a_mask[pp] >> tap) & 1u) ? a_off[pp] + (unsigned)tap_off : kInvalid, 0);
+    } else {
+      // stem: C = 4, one tap per 16-B chunk, taps 49..55 are K padding
+      const int tap = kt * 8 + chunk;
+      const int ky = tap / 7, kx = tap - ky * 7;
+#pragma unroll
+      for (int pp = 0; pp < APASS; ++pp) {
+        const int iy = a_iy[pp] + ky, ix = a_ix[pp] + kx;
+        const bool ok = tap < 49 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        ra[pp] = buf_load4(rsrcA, ok ? a_off[pp] + (unsigned)((iy * p.Wi + ix) * 16) : kInvalid, 0);
+      }
     }
 #pragma unroll
-    for (int pp = 0; pp < BPASS; ++pp)
-      rb[pp] = *reinterpret_cast<const f32x4 *>(wrow + (size_t)(32 * pp) * p.Kp + kt * kBK);
+    for (int pp = 0; pp < BPASS; ++pp) rb[pp] = buf_load4(rsrcB, b_off[pp], kbytes);
   };
 
   auto lstore = [&](int buf) {
@@ -162,35 +224,48 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -------------
+  // ---- epilogue ---------------------------------------------------------------------------------
+  // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Stage the BM x BN tile in
+  // LDS (all operand reads finished at the barrier above), then stream it out row-major.
+  float *Cs = smem;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WTN + j * 32 + l31;
-    const float b = p.bias[n];
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mbase = m0 + wm * WTM + i * 32 + 4 * half;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = mbase + (e & 3) + 8 * (e >> 2);
-        if (m < p.M) {
-          const size_t o = (size_t)m * p.Cout + n;
-          float v = acc[i][j][e] + b;
-          if (p.res) v += p.res[o];
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.y[o] = v;
-        }
+      for (int e = 0; e < 16; ++e)
+        Cs[(wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * CLD + wn * WTN + j * 32 + l31] = acc[i][j][e];
+  __syncthreads();
+
+  constexpr int TPR = BN / 4;          // threads per output row
+  constexpr int RPP = 256 / TPR;       // rows per pass
+  const int ecol = (tid % TPR) * 4, erow = tid / TPR;
+  const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
+#pragma unroll 4
+  for (int rr = erow; rr < BM; rr += RPP) {
+    const int m = m0 + rr;
+    if (m < p.M) {
+      const size_t o = (size_t)m * p.Cout + n0 + ecol;
+      f32x4 v = *reinterpret_cast<const f32x4 *>(Cs + rr * CLD + ecol);
+      v += bias;
+      if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + o);
+      if (p.relu) {
+        v[0] = fmaxf(v[0], 0.f);
+        v[1] = fmaxf(v[1], 0.f);
+        v[2] = fmaxf(v[2], 0.f);
+        v[3] = fmaxf(v[3], 0.f);
       }
+      *reinterpret_cast<f32x4 *>(p.y + o) = v;
     }
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS>
+template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT>
 static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
   p.ntm = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   const dim3 grid((unsigned)(p.ntm * p.ntn));
-  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WGM, WGN, KS>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WGM, WGN, KS, SHIFT>), grid, dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
@@ -208,23 +283,28 @@ void conv_tile_shape(const ConvParams &p, int *bm, int *bn) {
   *bn = BN;
 }
 
-template <int KS>
+template <int KS, bool SHIFT>
 static hipError_t launch_conv_ks(const ConvParams &p, hipStream_t s) {
   int bm, bn;
   conv_tile_shape(p, &bm, &bn);
-  if (bm == 128 && bn == 128) return launch_conv_t<128, 128, 2, 2, KS>(p, s);
-  if (bm == 128 && bn == 64) return launch_conv_t<128, 64, 2, 2, KS>(p, s);
-  return launch_conv_t<64, 64, 2, 2, KS>(p, s);
+  if (bm == 128 && bn == 128) return launch_conv_t<128, 128, 2, 2, KS, SHIFT>(p, s);
+  if (bm == 128 && bn == 64) return launch_conv_t<128, 64, 2, 2, KS, SHIFT>(p, s);
+  return launch_conv_t<64, 64, 2, 2, KS, SHIFT>(p, s);
 }
 
 hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s) {
   if (p.Cout % 64 != 0 || p.Kp % kBK != 0 || p.M <= 0) return hipErrorInvalidValue;
   if ((1 << p.logC4) * 4 != p.C) return hipErrorInvalidValue;
+  if (ks != 7 && p.C % kBK != 0) return hipErrorInvalidValue;
   if (p.T > 0 && (ks != 1 || p.stride != 1 || p.N % p.T != 0 || p.fold % 4 != 0)) return hipErrorInvalidValue;
+  // 32-bit byte offsets inside a workgroup's rebased window: a tile touches at most
+  // BM/(Ho*Wo) + 4 input frames.
+  const double frames = 128.0 / ((double)p.Ho * p.Wo) + 4.0;
+  if (frames * (double)p.Hi * p.Wi * p.C * 4.0 > 2.0e9) return hipErrorInvalidValue;
   switch (ks) {
-    case 1: return launch_conv_ks<1>(p, s);
-    case 3: return launch_conv_ks<3>(p, s);
-    case 7: return launch_conv_ks<7>(p, s);
+    case 1: return p.T > 0 ? launch_conv_ks<1, true>(p, s) : launch_conv_ks<1, false>(p, s);
+    case 3: return launch_conv_ks<3, false>(p, s);
+    case 7: return launch_conv_ks<7, false>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
