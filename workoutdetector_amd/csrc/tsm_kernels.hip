@@ -50,7 +50,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT>
+template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES>
 __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   static_assert(!SHIFT || KS == 1, "the temporal shift is fused into 1x1 convs only");
@@ -191,25 +191,43 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  auto compute = [&](int buf) {
+  // Fragment registers are double-buffered across the four 8-deep k-groups of a K-step so that the
+  // LDS latency of group kk+1 hides under the 16 MFMAs (1024 cycles) of group kk.
+  f32x4 af[2][TM], bf[2][TN];
+  auto frag_load = [&](int buf, int kk, int set) {
     const float *As = smem + buf * (BM + BN) * kLds + (wm * WTM + l31) * kLds + half * 4;
     const float *Bs = smem + buf * (BM + BN) * kLds + BM * kLds + (wn * WTN + l31) * kLds + half * 4;
 #pragma unroll
-    for (int kk = 0; kk < kBK / 8; ++kk) {
-      f32x4 af[TM], bf[TN];
+    for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const f32x4 *>(As + i * 32 * kLds + kk * 8);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(As + i * 32 * kLds + kk * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * kLds + kk * 8);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-    }
+    for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * kLds + kk * 8);
   };
+  auto mfma_group = [&](int set) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][s], bf[set][j][s], acc[i][j], 0, 0, 0);
+  };
+
+  // Residual tile: fetched before the K loop (it does not depend on it) in the epilogue's own
+  // row-major 16-B mapping, so its HBM latency hides under the MFMAs.  Rows past M read as zeros.
+  constexpr int TPR = BN / 4;          // threads per output row
+  constexpr int RPP = 256 / TPR;       // rows per pass
+  constexpr int EPASS = BM / RPP;
+  const int ecol = (tid % TPR) * 4, erow = tid / TPR;
+  f32x4 rres[RES ? EPASS : 1];
+  if (RES) {
+    const size_t r_bytes = ((size_t)p.M - m0) * p.Cout * 4;
+    const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.res + (size_t)m0 * p.Cout), 0,
+        (int)(r_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : r_bytes), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < EPASS; ++k)
+      rres[k] = buf_load4(rsrcR, (unsigned)(((erow + k * RPP) * p.Cout + n0 + ecol) * 4), 0);
+  }
 
   // ---- main loop: register-staged double buffer, one barrier per K-step ------------------------
   const int nk = p.Kp / kBK;
@@ -218,8 +236,13 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
+    frag_load(cur, 0, 0);
     if (kt + 1 < nk) gload(kt + 1);  // global loads fly under the MFMAs below
-    compute(cur);
+#pragma unroll
+    for (int kk = 0; kk < kBK / 8; ++kk) {
+      if (kk + 1 < kBK / 8) frag_load(cur, kk + 1, (kk + 1) & 1);
+      mfma_group(kk & 1);
+    }
     if (kt + 1 < nk) lstore(cur ^ 1);
     __syncthreads();
   }
@@ -237,35 +260,32 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
         Cs[(wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * CLD + wn * WTN + j * 32 + l31] = acc[i][j][e];
   __syncthreads();
 
-  constexpr int TPR = BN / 4;          // threads per output row
-  constexpr int RPP = 256 / TPR;       // rows per pass
-  const int ecol = (tid % TPR) * 4, erow = tid / TPR;
   const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
-#pragma unroll 4
-  for (int rr = erow; rr < BM; rr += RPP) {
+#pragma unroll
+  for (int k = 0; k < EPASS; ++k) {
+    const int rr = erow + k * RPP;
     const int m = m0 + rr;
     if (m < p.M) {
-      const size_t o = (size_t)m * p.Cout + n0 + ecol;
       f32x4 v = *reinterpret_cast<const f32x4 *>(Cs + rr * CLD + ecol);
       v += bias;
-      if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + o);
+      if (RES) v += rres[k];
       if (p.relu) {
         v[0] = fmaxf(v[0], 0.f);
         v[1] = fmaxf(v[1], 0.f);
         v[2] = fmaxf(v[2], 0.f);
         v[3] = fmaxf(v[3], 0.f);
       }
-      *reinterpret_cast<f32x4 *>(p.y + o) = v;
+      *reinterpret_cast<f32x4 *>(p.y + (size_t)m * p.Cout + n0 + ecol) = v;
     }
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT>
+template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES>
 static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
   p.ntm = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   const dim3 grid((unsigned)(p.ntm * p.ntn));
-  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WGM, WGN, KS, SHIFT>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WGM, WGN, KS, SHIFT, RES>), grid, dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
@@ -283,13 +303,13 @@ void conv_tile_shape(const ConvParams &p, int *bm, int *bn) {
   *bn = BN;
 }
 
-template <int KS, bool SHIFT>
+template <int KS, bool SHIFT, bool RES>
 static hipError_t launch_conv_ks(const ConvParams &p, hipStream_t s) {
   int bm, bn;
   conv_tile_shape(p, &bm, &bn);
-  if (bm == 128 && bn == 128) return launch_conv_t<128, 128, 2, 2, KS, SHIFT>(p, s);
-  if (bm == 128 && bn == 64) return launch_conv_t<128, 64, 2, 2, KS, SHIFT>(p, s);
-  return launch_conv_t<64, 64, 2, 2, KS, SHIFT>(p, s);
+  if (bm == 128 && bn == 128) return launch_conv_t<128, 128, 2, 2, KS, SHIFT, RES>(p, s);
+  if (bm == 128 && bn == 64) return launch_conv_t<128, 64, 2, 2, KS, SHIFT, RES>(p, s);
+  return launch_conv_t<64, 64, 2, 2, KS, SHIFT, RES>(p, s);
 }
 
 hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s) {
@@ -302,9 +322,11 @@ hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s) {
   const double frames = 128.0 / ((double)p.Ho * p.Wo) + 4.0;
   if (frames * (double)p.Hi * p.Wi * p.C * 4.0 > 2.0e9) return hipErrorInvalidValue;
   switch (ks) {
-    case 1: return p.T > 0 ? launch_conv_ks<1, true>(p, s) : launch_conv_ks<1, false>(p, s);
-    case 3: return launch_conv_ks<3, false>(p, s);
-    case 7: return launch_conv_ks<7, false>(p, s);
+    case 1:
+      if (p.res) return p.T > 0 ? hipErrorInvalidValue : launch_conv_ks<1, false, true>(p, s);
+      return p.T > 0 ? launch_conv_ks<1, true, false>(p, s) : launch_conv_ks<1, false, false>(p, s);
+    case 3: return p.res ? hipErrorInvalidValue : launch_conv_ks<3, false, false>(p, s);
+    case 7: return p.res ? hipErrorInvalidValue : launch_conv_ks<7, false, false>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
