@@ -17,6 +17,7 @@ namespace tsm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // LDS row stride in floats: 32 data + 4 pad.  With ds_read_b128 (16-lane groups, 64 banks) the 16
 // rows of a group land on 16 distinct 4-bank slots (row*36 mod 64 is a permutation of multiples
@@ -135,52 +136,70 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
 
   f32x4 ra[APASS], rb[BPASS];
 
-  auto gload = [&](int kt) {
-    const unsigned kbytes = (unsigned)kt * (kBK * 4);
-    if (KS == 1) {
-      if (SHIFT) {
-        const int c = kt * kBK + chunk * 4;
-        const bool fwd = c < p.fold, bwd = c < 2 * p.fold;
-#pragma unroll
-        for (int pp = 0; pp < APASS; ++pp)
-          ra[pp] = buf_load4(rsrcA, fwd ? a_offp[pp] : (bwd ? a_offm[pp] : a_off[pp]), kbytes);
+  // Loader work is cut into NITEMS = APASS + BPASS single-instruction items (one 16-B buffer load or
+  // one ds_write_b128 each) so the main loop can drop one item between consecutive MFMAs.
+  // A dead K-step (past the end of K) ORs kInvalid into every offset, so its loads return zeros
+  // without touching memory and the loop body stays branch-free.
+  constexpr int NITEMS = APASS + BPASS;
+  struct KStep {  // wave-uniform per-K-step scalars
+    unsigned kbytes;
+    int tap, tap_off;
+    unsigned dead;  // 0 for a live step, kInvalid for a step past the end of K (pure arithmetic, no select)
+    unsigned mp, mm, m0;  // SHIFT: lane masks choosing the t+1 / t-1 / t source frame for this thread's chunk
+  };
+  auto kstep = [&](int kt, int nk_) {
+    KStep k;
+    k.kbytes = (unsigned)kt * (kBK * 4);
+    k.dead = (~(unsigned)((kt - nk_) >> 31)) & kInvalid;
+    k.mp = k.mm = 0u;
+    k.m0 = ~0u;
+    if (SHIFT) {
+      // channels [0,fold) <- frame t+1, [fold,2fold) <- frame t-1, rest <- frame t.  Kept as AND/OR
+      // masks: a three-way select over the per-row offset arrays is turned into a scratch-memory
+      // table by the compiler, which serialises the loader behind vmcnt(0).
+      const int c = kt * kBK + chunk * 4;
+      k.mp = 0u - (unsigned)(c < p.fold);
+      k.mm = (0u - (unsigned)(c < 2 * p.fold)) & ~k.mp;
+      k.m0 = ~(k.mp | k.mm);
+    }
+    k.tap = 0;
+    k.tap_off = 0;
+    if (KS == 3) {  // C >= 32 so a K-step never straddles a tap: tap and its offset are scalars
+      k.tap = (kt * kBK) >> (p.logC4 + 2);
+      const int c0 = kt * kBK - k.tap * p.C;
+      const int ky = k.tap / 3, kx = k.tap - ky * 3;
+      k.tap_off = ((ky * p.Wi + kx) * p.C + c0) * 4;
+    }
+    return k;
+  };
+  auto gload_item = [&](const KStep &k, int kt, int item) {
+    if (item < APASS) {
+      const int pp = item;
+      if (KS == 1) {
+        unsigned off = a_off[pp];
+        if (SHIFT) off = (a_offp[pp] & k.mp) | (a_offm[pp] & k.mm) | (a_off[pp] & k.m0);
+        ra[pp] = buf_load4(rsrcA, off | k.dead, k.kbytes);
+      } else if (KS == 3) {
+        ra[pp] = buf_load4(rsrcA, (((a_mask[pp] >> k.tap) & 1u) ? a_off[pp] + (unsigned)k.tap_off : kInvalid) | k.dead, 0);
       } else {
-#pragma unroll
-        for (int pp = 0; pp < APASS; ++pp) ra[pp] = buf_load4(rsrcA, a_off[pp], kbytes);
-      }
-    } else if (KS == 3) {
-      // C >= 32 so a K-step never straddles a tap: tap and its offset are wave-uniform scalars
-      const int tap = (kt * kBK) >> (p.logC4 + 2);
-      const int c0 = kt * kBK - tap * p.C;
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const int tap_off = ((ky * p.Wi + kx) * p.C + c0) * 4;
-#pragma unroll
-      for (int pp = 0; pp < APASS; ++pp)
-        ra[pp] = buf_load4(rsrcA, ((a_mask[pp] >> tap) & 1u) ? a_off[pp] + (unsigned)tap_off : kInvalid, 0);
-    } else {
-      // stem: C = 4, one tap per 16-B chunk, taps 49..55 are K padding
-      const int tap = kt * 8 + chunk;
-      const int ky = tap / 7, kx = tap - ky * 7;
-#pragma unroll
-      for (int pp = 0; pp < APASS; ++pp) {
+        // stem: C = 4, one tap per 16-B chunk, taps 49..55 are K padding
+        const int tap = kt * 8 + chunk;
+        const int ky = tap / 7, kx = tap - ky * 7;
         const int iy = a_iy[pp] + ky, ix = a_ix[pp] + kx;
         const bool ok = tap < 49 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        ra[pp] = buf_load4(rsrcA, ok ? a_off[pp] + (unsigned)((iy * p.Wi + ix) * 16) : kInvalid, 0);
+        ra[pp] = buf_load4(rsrcA, (ok ? a_off[pp] + (unsigned)((iy * p.Wi + ix) * 16) : kInvalid) | k.dead, 0);
       }
+    } else {
+      const int pp = item - APASS;
+      rb[pp] = buf_load4(rsrcB, b_off[pp] | k.dead, k.kbytes);
     }
-#pragma unroll
-    for (int pp = 0; pp < BPASS; ++pp) rb[pp] = buf_load4(rsrcB, b_off[pp], kbytes);
   };
-
-  auto lstore = [&](int buf) {
+  auto lstore_item = [&](int buf, int item) {
     float *As = smem + buf * (BM + BN) * kLds;
-    float *Bs = As + BM * kLds;
-#pragma unroll
-    for (int pp = 0; pp < APASS; ++pp)
-      *reinterpret_cast<f32x4 *>(As + (lrow + 32 * pp) * kLds + chunk * 4) = ra[pp];
-#pragma unroll
-    for (int pp = 0; pp < BPASS; ++pp)
-      *reinterpret_cast<f32x4 *>(Bs + (lrow + 32 * pp) * kLds + chunk * 4) = rb[pp];
+    if (item < APASS)
+      *reinterpret_cast<f32x4 *>(As + (lrow + 32 * item) * kLds + chunk * 4) = ra[item];
+    else
+      *reinterpret_cast<f32x4 *>(As + BM * kLds + (lrow + 32 * (item - APASS)) * kLds + chunk * 4) = rb[item - APASS];
   };
 
   f32x16 acc[TM][TN];
@@ -202,7 +221,30 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) bf[set][j] = *reinterpret_cast<const f32x4 *>(Bs + j * 32 * kLds + kk * 8);
   };
-  auto mfma_group = [&](int set) {
+  // 4*TM*TN MFMAs of one k-group; `inject(item)` is called NITEMS times, spread evenly between them,
+  // and a scheduling fence pins each injected instruction behind the MFMA it follows: the matrix
+  // pipe executes an issued MFMA for 64 cycles, during which the wave may issue the injected item.
+  constexpr int NMFMA = 4 * TM * TN;
+  auto mfma_group = [&](int set, auto &&inject) {
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][s], bf[set][j][s], acc[i][j], 0, 0, 0);
+          ++cnt;
+          const int done = (cnt * NITEMS) / NMFMA, before = ((cnt - 1) * NITEMS) / NMFMA;
+#pragma unroll
+          for (int it = before; it < done; ++it) {
+            inject(it);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+  };
+  auto no_inject = [](int) {};
+  auto mfma_plain = [&](int set) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -211,6 +253,7 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][i][s], bf[set][j][s], acc[i][j], 0, 0, 0);
   };
+  (void)no_inject;
 
   // Residual tile: fetched before the K loop (it does not depend on it) in the epilogue's own
   // row-major 16-B mapping, so its HBM latency hides under the MFMAs.  Rows past M read as zeros.
@@ -229,22 +272,47 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
       rres[k] = buf_load4(rsrcR, (unsigned)(((erow + k * RPP) * p.Cout + n0 + ecol) * 4), 0);
   }
 
-  // ---- main loop: register-staged double buffer, one barrier per K-step ------------------------
+  // ---- main loop -------------------------------------------------------------------------------
+  // Two LDS buffers, one barrier per K-step.  Iteration kt multiplies tile kt out of buf[kt&1] in four
+  // k-groups of 4*TM*TN MFMAs:
+  //   group 0            plain
+  //   group 1            + ds_writes of tile kt+1 (registers, loaded during iteration kt-1) into the
+  //                        other buffer: its last readers finished before the barrier of kt-1
+  //   group 2            + buffer loads of tile kt+2, which then have a whole K-step to land
+  //   barrier
+  //   group 3            register-only, issued AFTER the barrier so that it covers the LDS latency of
+  //                        the next tile's first fragments (read right after the barrier)
+  // One barrier per step suffices: tile kt+1 is complete in LDS before it, and nobody overwrites
+  // buf[kt&1] before the next barrier.  The body is straight-line.
   const int nk = p.Kp / kBK;
-  gload(0);
-  lstore(0);
+  {
+    const KStep k0 = kstep(0, nk);
+#pragma unroll
+    for (int it = 0; it < NITEMS; ++it) gload_item(k0, 0, it);
+#pragma unroll
+    for (int it = 0; it < NITEMS; ++it) lstore_item(0, it);
+    const KStep k1 = kstep(1, nk);
+#pragma unroll
+    for (int it = 0; it < NITEMS; ++it) gload_item(k1, 1, it);
+  }
   __syncthreads();
+  frag_load(0, 0, 0);
+  frag_load(0, 1, 1);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    frag_load(cur, 0, 0);
-    if (kt + 1 < nk) gload(kt + 1);  // global loads fly under the MFMAs below
-#pragma unroll
-    for (int kk = 0; kk < kBK / 8; ++kk) {
-      if (kk + 1 < kBK / 8) frag_load(cur, kk + 1, (kk + 1) & 1);
-      mfma_group(kk & 1);
-    }
-    if (kt + 1 < nk) lstore(cur ^ 1);
+    const KStep k2 = kstep(kt + 2, nk);
+    mfma_plain(0);
+    frag_load(cur, 2, 0);
+    mfma_group(1, [&](int it) { lstore_item(cur ^ 1, it); });
+    frag_load(cur, 3, 1);
+    mfma_group(0, [&](int it) { gload_item(k2, kt + 2, it); });
     __syncthreads();
+    frag_load(cur ^ 1, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_plain(1);
+    __builtin_amdgcn_sched_barrier(0);
+    frag_load(cur ^ 1, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
@@ -260,23 +328,25 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
         Cs[(wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * CLD + wn * WTN + j * 32 + l31] = acc[i][j][e];
   __syncthreads();
 
+  // Stores go through a descriptor that ends at row M: rows past the end are dropped by the range
+  // check, which keeps the epilogue branch-free (no per-pass wait on earlier stores).
+  const size_t y_bytes = ((size_t)p.M - m0) * p.Cout * 4;
+  const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+      p.y + (size_t)m0 * p.Cout, 0, (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
   const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
+  const float floor_ = p.relu ? 0.f : -INFINITY;  // ReLU as a branch-free clamp
 #pragma unroll
   for (int k = 0; k < EPASS; ++k) {
     const int rr = erow + k * RPP;
-    const int m = m0 + rr;
-    if (m < p.M) {
-      f32x4 v = *reinterpret_cast<const f32x4 *>(Cs + rr * CLD + ecol);
-      v += bias;
-      if (RES) v += rres[k];
-      if (p.relu) {
-        v[0] = fmaxf(v[0], 0.f);
-        v[1] = fmaxf(v[1], 0.f);
-        v[2] = fmaxf(v[2], 0.f);
-        v[3] = fmaxf(v[3], 0.f);
-      }
-      *reinterpret_cast<f32x4 *>(p.y + (size_t)m * p.Cout + n0 + ecol) = v;
-    }
+    f32x4 v = *reinterpret_cast<const f32x4 *>(Cs + rr * CLD + ecol);
+    v += bias;
+    if (RES) v += rres[k];
+    v[0] = fmaxf(v[0], floor_);
+    v[1] = fmaxf(v[1], floor_);
+    v[2] = fmaxf(v[2], floor_);
+    v[3] = fmaxf(v[3], floor_);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcY,
+                                           (int)((rr * p.Cout + n0 + ecol) * 4), 0, 0);
   }
 }
 
