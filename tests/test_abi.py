@@ -1,0 +1,79 @@
+"""The C-ABI library builds, loads and exports exactly what include/tsm_hip.h declares (CPU, no compute)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from workoutdetector_amd import _lib
+    from workoutdetector_amd.build import build_library
+    build_library()
+    return _lib.load()
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'tsm_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(tsm_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_symbols_are_exported(lib):
+    from workoutdetector_amd import _lib
+    from workoutdetector_amd.build import LIB_PATH
+    declared = _declared()
+    assert declared == sorted(_lib.EXPORTS)
+    out = subprocess.run(['nm', '-D', '--defined-only', LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r' T (tsm_[a-z0-9_]+)', out)))
+    assert exported == declared
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+
+
+def test_abi_version_and_config_layout(lib):
+    from workoutdetector_amd import _lib
+    assert lib.tsm_abi_version() == _lib.ABI_VERSION == 1
+    assert ctypes.sizeof(_lib.TsmConfig) == 40          # 10 x int32, matches struct tsm_config
+
+
+def test_create_rejects_bad_config_before_touching_the_gpu(lib):
+    from workoutdetector_amd import _lib
+    h = ctypes.c_void_p()
+    cfg = _lib.TsmConfig(4, 12, 8, 224, 224, 8, 1, 1, 0, 0)          # wrong struct_size
+    assert lib.tsm_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and not h.value
+    assert b'struct_size' in lib.tsm_last_error(None)
+    cfg = _lib.TsmConfig(40, 12, 8, 224, 224, 7, 1, 1, 0, 0)         # shift_div 7 unsupported
+    assert lib.tsm_create(ctypes.byref(cfg), ctypes.byref(h)) == -7
+    cfg = _lib.TsmConfig(40, 0, 8, 224, 224, 8, 1, 1, 0, 0)
+    assert lib.tsm_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    lib.tsm_destroy(None)                                              # must be a no-op
+    assert lib.tsm_forward(None, None, 0, 0, 1, None, None) == -1
+
+
+def test_engine_fails_loudly_without_gpu():
+    """No CPU fallback: on a box without a GPU construction raises (on a GPU box this test is moot)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from workoutdetector_amd._lib import TsmError
+    from workoutdetector_amd.engine import TsmEngine, create_model
+    with pytest.raises(TsmError) as ei:
+        TsmEngine(max_clips=1)
+    assert ei.value.status == -2
+    with pytest.raises(RuntimeError):
+        create_model(num_class=12, device='cpu')
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under workoutdetector_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'workoutdetector_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f

@@ -1,0 +1,108 @@
+"""Config 3 of BASELINE.json: a pull_up-shaped frame stream through the whole path on the GPU --
+clip windows -> transform -> HIP engine -> softmax/threshold -> pred_to_count -- against the CPU oracle.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import counting_oracle, transform_oracle, tsm_oracle
+from tests._stub import synthetic_video
+from tests._util import assert_close, fit_probe_fc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def probe_engine(hip_lib, sd0):
+    """Seed-0 trunk + a classifier fitted (on the oracle) to flip between classes 4/5 with brightness."""
+    from workoutdetector_amd.engine import TsmEngine
+    sd = dict(sd0)
+    probe = torch.from_numpy(synthetic_video(11, 96, 90, 52, period=24))
+    sd['fc.weight'], sd['fc.bias'] = fit_probe_fc(sd0, probe)
+    eng = TsmEngine(num_class=12, num_segments=8, max_clips=32, state_dict=sd)
+    yield eng, sd
+    eng.close()
+
+
+def test_stream_counts_identical_to_oracle(probe_engine):
+    """Non-trivial integer repetition count, identical between the HIP path and the oracle path; logits within
+    fp32 rtol 1e-3.  Stream is portrait like RepCount's stu* clips (scaled down to keep the CPU oracle short)."""
+    from workoutdetector_amd import inference_count as ic
+    from workoutdetector_amd.transform import build_test_transform
+    eng, sd = probe_engine
+    vid = torch.from_numpy(synthetic_video(23, 140, 90, 52, period=24))      # 18 clips, tail zero-padded
+    got = ic.video_clip_logits(eng, vid, build_test_transform(False), batch_clips=32)
+    want = torch.cat([tsm_oracle.tsm_forward(sd, transform_oracle.clip_to_input(transform_oracle.make_clip(vid, s)))
+                      for s in range(0, 140, 8)])
+    assert_close(got.numpy(), want.numpy(), rtol=1e-3, atol_scale=1e-4, what='stream logits')
+    from workoutdetector_amd.counting import pred_to_count, scores_to_preds
+    states = scores_to_preds(got.tolist())
+    assert states == counting_oracle.scores_to_preds(want.tolist())
+    count, reps = pred_to_count(states, 8)
+    assert (count, reps) == counting_oracle.pred_to_count(states, 8)
+    assert count >= 3 and set(states) <= {4, 5, -1}, (states, count)         # ~140/24 periods of bright->dark
+
+
+def test_full_size_stream_properties(probe_engine, tmp_path):
+    """BASELINE config 3 at full size: 1080 frames of 360x206 uint8 -> 135 clips.  Size-independent
+    properties instead of the oracle: batch invariance (B=32 chunks vs one clip at a time), the
+    reference's clip-by-clip inference_video path, streaming == offline counts, JSON round trip."""
+    from workoutdetector_amd import eval as tsm_eval
+    from workoutdetector_amd import inference_count as ic
+    from workoutdetector_amd.counting import pred_to_count, scores_to_preds
+    from workoutdetector_amd.transform import build_test_transform
+    eng, _ = probe_engine
+    vid = torch.from_numpy(synthetic_video(5, 1080, 360, 206, period=36))
+    tf = build_test_transform(False)
+    batched = ic.video_clip_logits(eng, vid, tf, batch_clips=32)
+    assert tuple(batched.shape) == (135, 12)
+    single = ic.video_clip_logits(eng, vid, tf, batch_clips=1)
+    assert torch.equal(batched, single)
+    for s in (0, 8 * 67, 8 * 134):                                            # incl. the zero-padded tail clip
+        ref_style = ic.inference_video(eng, ic.make_clip(vid, s).cuda(), transform=tf)
+        np.testing.assert_array_equal(np.float32([v for _, v in ref_style]), batched[s // 8].numpy())
+    states = scores_to_preds(batched.tolist())
+    count, reps = pred_to_count(states, 8)
+    assert count >= 20                                                        # 1080 / 36 = 30 brightness periods
+    scores = ic.scores_dict(batched, 1080)
+    path = tmp_path / 'v.score.json'
+    json.dump(dict(scores=scores, action='pull_up'), open(path, 'w'))
+    back = json.load(open(path))['scores']
+    assert tsm_eval.preds_from_scores(back, softmax=True) == states
+    # streaming windows (stride 8, no overlap) see different frames than the sparse offline windows, but must
+    # be self-consistent with their own offline evaluation
+    c2, r2 = ic.count_by_video_model(eng, iter(vid[:400].numpy()))
+    st2 = []
+    for i in range(0, 400, 8):
+        sc = [v for _, v in ic.inference_video(eng, vid[i:i + 8].float(), transform=tf)]
+        st2.append(scores_to_preds([sc])[0])
+    assert (c2, r2) == pred_to_count(st2, 8)
+
+
+def test_inference_dataset_on_gpu_engine(probe_engine, tmp_path, golden_dir):
+    """inference_dataset counterpart end to end with the real engine on two synthetic RepCount videos."""
+    import pandas as pd
+    from workoutdetector_amd import inference_count as ic
+    eng, sd = probe_engine
+    anno = pd.read_csv(f'{golden_dir}/repcount_annotation.csv', index_col=0)
+    rows = anno[anno['name'].isin(['stu1_40.mp4', 'stu5_32.mp4'])].copy()
+    rows['name'] = [n.replace('.mp4', '.npy') for n in rows['name']]
+    root = tmp_path / 'RepCount'
+    (root / 'videos' / 'test').mkdir(parents=True)
+    rows.to_csv(root / 'annotation.csv')
+    frames = {'stu1_40.npy': 336, 'stu5_32.npy': 52}
+    for i, name in enumerate(rows['name']):
+        np.save(root / 'videos' / 'test' / name, synthetic_video(40 + i, frames[name], 120, 68, period=28))
+    out = str(tmp_path / 'out')
+    ic.inference_dataset(eng, ['test'], out, checkpoint='seed0+probe', data_root=str(root))
+    d = json.load(open(os.path.join(out, 'stu1_40.npy.score.json')))
+    assert d['total_frames'] == 336 and len(d['scores']) == 42 and d['action'] == 'pull_up'
+    # spot-check three clips against the oracle
+    vid = torch.from_numpy(np.load(root / 'videos' / 'test' / 'stu1_40.npy'))
+    for s in (0, 160, 328):
+        want = tsm_oracle.tsm_forward(sd, transform_oracle.clip_to_input(transform_oracle.make_clip(vid, s)))[0]
+        got = np.float32([d['scores'][str(s)][str(c)] for c in range(12)])
+        assert_close(got, want.numpy(), rtol=1e-3, atol_scale=1e-4, what=f'clip {s}')
