@@ -10,9 +10,14 @@ every rank runs its own batch (weak scaling) and the only exchange is the RCCL a
 logits, which is inside the timed step.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      algorithmic FLOPs of the conv_igemm_f32 launches of one forward (65.395 GFLOP/clip,
-                SURVEY.md section 8d) / the forward's duration measured with HIP events on the launch
-                stream, against the exact-fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md)
+  roofline      the dominant kernel is conv_igemm_f32<128,128,2,2,3,false,false>: the 3x3 convolutions of
+                layer2..layer4 (13 launches per forward, one third of the forward's time).  Every one of
+                those launches does the same algorithmic work, 115.6 MMAC/frame x 2 x frames (59.19 GFLOP
+                at batch 32); `achieved` = that / the launches' average duration, measured with HIP-event
+                pairs recorded around each launch on the launch stream during the timed steps
+                (tsm_set_layer_timing / tsm_layer_times), against the exact-fp32 MFMA peak (157.3 TFLOP/s,
+                MI355X_MICROARCH.md).  `forward_achieved` / `forward_frac` price the whole forward
+                (65.395 GFLOP/clip, SURVEY.md section 8d, all 53 conv launches + pool/head kernels).
   cpu_baseline  the CPU oracle (oracle/tsm_oracle.py, torch-CPU fp32, the same graph; the reference's
                 own onnxruntime CPU path cannot run here) timed on this box's host cores, batch 1 like
                 the reference (utils/inference_count.py:272), bounded to ~15 s
@@ -50,6 +55,19 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return min(n, int(os.environ.get('TSM_BENCH_CPU_THREADS', '16')))
+
+
+def measured_traffic(b, t, h, w):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json),
+    only when they were collected on this exact configuration; bench.py cannot run PMC passes itself."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    except (OSError, ValueError):
+        return None
+    c = d.get('config', {})
+    if (c.get('clips_per_gpu'), c.get('num_segments'), c.get('height'), c.get('width')) != (b, t, h, w):
+        return None
+    return d.get('hbm_bytes_per_launch')
 
 
 def cpu_baseline(sd_np, t, h, w, budget_s=15.0):
@@ -128,6 +146,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    n_timed = min(args.steps, 64)
+    eng.set_layer_timing(n_timed, only_conv3x3=True)   # HIP-event pairs around the dominant kernel's launches
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -138,12 +158,16 @@ def main():
     elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(out).all())
 
-    # Per-forward kernel time from HIP events recorded inside tsm_forward on the launch stream
-    # (separate pass so that the event sync does not sit inside the wall-clock region above).
-    ev_ms = []
+    # Per-launch durations of the timed forwards (events were recorded inside the timed region; reading
+    # them here keeps the host syncs out of it).
+    per_launch = [eng.layer_times_ms(i) for i in range(n_timed)]
+    eng.set_layer_timing(0)
+    # Whole-forward kernel time (one HIP-event pair around all launches of a forward), outside the
+    # wall-clock region because reading it synchronises.
+    fwd_ev_ms = []
     for _ in range(min(args.steps, 10)):
         eng.forward_device(clips, out=logits)
-        ev_ms.append(eng.last_forward_ms)
+        fwd_ev_ms.append(eng.last_forward_ms)
     torch.cuda.synchronize()
 
     t_max = torch.tensor([elapsed], device='cuda')
@@ -155,8 +179,17 @@ def main():
         clips_total = B * world * args.steps
         value = clips_total / elapsed
         gflop = flops_per_clip(T, H, W) / 1e9
-        ev = sorted(ev_ms)[len(ev_ms) // 2]
-        achieved = gflop * B / ev  # GFLOP / ms == TFLOP/s
+        fwd_ms = sorted(fwd_ev_ms)[len(fwd_ev_ms) // 2]
+        fwd_achieved = gflop * B / fwd_ms  # GFLOP / ms == TFLOP/s
+        from oracle.tsm_oracle import layer_table
+        frames = B * T
+        dom = [r for r in layer_table(H, W) if r['k'] == 3 and r['s'] >= 1 and not r['name'].startswith('layer1.')]
+        dom_gflop = {2.0 * r['macs'] * frames / 1e9 for r in dom}
+        assert len(dom_gflop) == 1, 'every 3x3 conv of ResNet-50 does the same work per frame'
+        dom_gflop = dom_gflop.pop()
+        dom_ms = [d[r['name']] for d in per_launch for r in dom]
+        dom_avg_ms = sum(dom_ms) / len(dom_ms)
+        achieved = dom_gflop / dom_avg_ms
         line = {
             'metric': 'clips/sec (8x3x224x224 TSM-R50)', 'value': round(value, 2), 'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -168,10 +201,15 @@ def main():
                        'weights': 'seeded random init (no trained weights offline)',
                        'parallelism': f'clip-sharded x{world}, RCCL all-gather of logits' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
-                         'kernel': 'conv_igemm_f32 (53 launches per forward, >99.9% of FLOPs)',
-                         'flops_per_launch_group': round(gflop * B, 3), 'group_ms': round(ev, 4),
-                         'peak_name': 'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), dense'},
+                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': measured_traffic(B, T, H, W),
+                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/traffic.json)',
+                         'kernel': 'conv_igemm_f32<128,128,2,2,3,false,false> (3x3 convs of layer2-4)',
+                         'gflop_per_launch': round(dom_gflop, 3), 'avg_launch_ms': round(dom_avg_ms, 4),
+                         'launches_timed': len(dom_ms),
+                         'peak_name': 'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), dense',
+                         'forward_achieved': round(fwd_achieved, 2),
+                         'forward_frac': round(fwd_achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         'forward_gflop': round(gflop * B, 3), 'forward_kernel_ms': round(fwd_ms, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, T, H, W)

@@ -113,6 +113,16 @@ int tsm_forward_tap(tsm_engine *e, const void *clips, int32_t memkind, int32_t l
  * stream the kernels ran on (ms); negative if none.  Synchronises on the stop event. */
 float tsm_last_forward_ms(tsm_engine *e);
 
+/* Per-launch timing for bench.py's roofline: keep HIP-event pairs around the kernel launches of the
+ * next `n_forwards` tsm_forward calls (0 switches it off; at most 64 are kept).  `only_conv3x3` != 0
+ * limits the pairs to the 3x3 convolutions (the dominant kernel), which keeps the marker overhead
+ * inside a timed region below 0.5 %; launches without a pair report -1.  tsm_layer_times
+ * synchronises on forward `forward_index` (0-based since the last tsm_set_layer_timing) and writes
+ * one duration in ms per launch, in launch order: pack_input, conv1 (stem), maxpool, then per block
+ * [downsample,] conv1, conv2, conv3, then head (pool + fc).  *n_out = number of launches. */
+int tsm_set_layer_timing(tsm_engine *e, int32_t n_forwards, int32_t only_conv3x3);
+int tsm_layer_times(tsm_engine *e, int32_t forward_index, float *ms_out, int32_t cap, int32_t *n_out);
+
 /* Per-op entry points (device pointers; used by the parity tests and as building blocks) ----- */
 
 /* NHWC temporal shift, x/y: [n_frames, hw, c]; n_frames % n_segment == 0; c % (4*fold_div)==0 */

@@ -90,6 +90,12 @@ struct tsm_engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool have_time = false;
   std::vector<void *> allocs;
+  // per-launch timing (tsm_set_layer_timing): timing[f] = events of forward f, 2 per launch
+  int timing_left = 0;
+  bool timing_only3x3 = false;
+  std::vector<std::vector<hipEvent_t>> timing;
+  std::vector<hipEvent_t> event_pool;
+  std::vector<hipEvent_t> *cur_timing = nullptr;
 };
 
 namespace {
@@ -199,6 +205,39 @@ struct Tap {
   bool hit = false;
 };
 
+// One event before and one after a launch when per-launch timing is armed for this forward.
+struct LaunchTimer {
+  tsm_engine *e;
+  hipStream_t s;
+  bool on;
+  bool skip;  // armed, but this launch is outside the selection: keep the slot, record nothing
+  LaunchTimer(tsm_engine *e_, hipStream_t s_, bool is3x3)
+      : e(e_), s(s_), on(e_->cur_timing != nullptr), skip(e_->timing_only3x3 && !is3x3) { mark(); }
+  ~LaunchTimer() { mark(); }
+  void mark() {
+    if (!on) return;
+    if (skip) {
+      e->cur_timing->push_back(nullptr);
+      return;
+    }
+    hipEvent_t ev = nullptr;
+    if (!e->event_pool.empty()) {
+      ev = e->event_pool.back();
+      e->event_pool.pop_back();
+    } else if (hipEventCreate(&ev) != hipSuccess) {
+      return;
+    }
+    (void)hipEventRecord(ev, s);
+    e->cur_timing->push_back(ev);
+  }
+};
+#define TSM_LAUNCH_K(e, s, is3x3, call) \
+  do {                                  \
+    LaunchTimer _lt((e), (s), (is3x3)); \
+    TSM_HIP((e), (call));               \
+  } while (0)
+#define TSM_LAUNCH(e, s, call) TSM_LAUNCH_K(e, s, false, call)
+
 // Enqueue the forward on `s`.  If `stage` is non-null, stop right after that stage and report it.
 int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, float *d_logits,
                 hipStream_t s, const char *stage, Tap *tap) {
@@ -211,16 +250,16 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     return TSM_OK;
   };
 
-  TSM_HIP(e, tsm::launch_pack_input(d_clips, e->d_in4, n, cfg.height, cfg.width,
-                                    layout == TSM_LAYOUT_NTCHW ? 1 : 0, s));
+  TSM_LAUNCH(e, s, tsm::launch_pack_input(d_clips, e->d_in4, n, cfg.height, cfg.width,
+                                          layout == TSM_LAYOUT_NTCHW ? 1 : 0, s));
   if (want("input")) return hit(e->d_in4, n, cfg.height, cfg.width, 4);
 
   float *cur = e->buf[0], *out = e->buf[1], *t1 = e->buf[2], *t2 = e->buf[3], *idb = e->buf[4];
   {
     tsm::ConvParams p = make_params(e->convs[0], e->d_in4, nullptr, t1, n, cfg.height, cfg.width, true, 0, 1);
-    TSM_HIP(e, tsm::launch_conv(p, 7, s));
+    TSM_LAUNCH(e, s, tsm::launch_conv(p, 7, s));
     if (want("conv1")) return hit(t1, n, e->h1, e->w1, 64);
-    TSM_HIP(e, tsm::launch_maxpool3x3s2(t1, cur, n, e->h1, e->w1, 64, s));
+    TSM_LAUNCH(e, s, tsm::launch_maxpool3x3s2(t1, cur, n, e->h1, e->w1, 64, s));
     if (want("stem")) return hit(cur, n, e->hp, e->wp, 64);
   }
   int h = e->hp, w = e->wp;
@@ -233,25 +272,25 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     const float *identity = cur;
     if (blk.down >= 0) {
       tsm::ConvParams pd = make_params(e->convs[blk.down], cur, nullptr, idb, n, h, w, false, 0, 1);
-      TSM_HIP(e, tsm::launch_conv(pd, 1, s));
+      TSM_LAUNCH(e, s, tsm::launch_conv(pd, 1, s));
       identity = idb;
     }
     tsm::ConvParams p1 = make_params(c1, cur, nullptr, t1, n, h, w, true, shiftT, cfg.shift_div);
-    TSM_HIP(e, tsm::launch_conv(p1, 1, s));
+    TSM_LAUNCH(e, s, tsm::launch_conv(p1, 1, s));
     if (want(name + ".conv1")) return hit(t1, n, h, w, c1.cout);
     tsm::ConvParams p2 = make_params(c2, t1, nullptr, t2, n, h, w, true, 0, 1);
-    TSM_HIP(e, tsm::launch_conv(p2, 3, s));
+    TSM_LAUNCH_K(e, s, true, tsm::launch_conv(p2, 3, s));
     if (want(name + ".conv2")) return hit(t2, n, ho, wo, c2.cout);
     tsm::ConvParams p3 = make_params(c3, t2, identity, out, n, ho, wo, true, 0, 1);
-    TSM_HIP(e, tsm::launch_conv(p3, 1, s));
+    TSM_LAUNCH(e, s, tsm::launch_conv(p3, 1, s));
     if (want(name)) return hit(out, n, ho, wo, c3.cout);
     std::swap(cur, out);
     h = ho; w = wo;
     if (++bi == kBlocks[li]) { bi = 0; ++li; }
   }
   if (stage) return fail(e, TSM_ERR_INVALID_ARG, std::string("unknown stage: ") + stage);
-  TSM_HIP(e, tsm::launch_head(cur, e->d_fcw, e->d_fcb, e->d_pooled, d_logits, n_clips, T, h * w, 2048,
-                              cfg.num_class, s));
+  TSM_LAUNCH(e, s, tsm::launch_head(cur, e->d_fcw, e->d_fcb, e->d_pooled, d_logits, n_clips, T, h * w, 2048,
+                                    cfg.num_class, s));
   return TSM_OK;
 }
 
@@ -322,6 +361,10 @@ void tsm_destroy(tsm_engine *e) {
   (void)hipSetDevice(e->cfg.device_id);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (void *p : e->allocs) (void)hipFree(p);
+  for (auto &v : e->timing)
+    for (hipEvent_t ev : v)
+      if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -426,8 +469,15 @@ int tsm_forward(tsm_engine *e, const void *clips, int32_t memkind, int32_t layou
     d_clips = e->d_in;
     d_out = e->d_logits;
   }
+  e->cur_timing = nullptr;
+  if (e->timing_left > 0) {
+    --e->timing_left;
+    e->timing.emplace_back();
+    e->cur_timing = &e->timing.back();
+  }
   TSM_HIP(e, hipEventRecord(e->ev0, s));
   rc = run_forward(e, d_clips, layout, n_clips, d_out, s, nullptr, nullptr);
+  e->cur_timing = nullptr;
   if (rc) return rc;
   TSM_HIP(e, hipEventRecord(e->ev1, s));
   e->have_time = true;
@@ -462,6 +512,36 @@ int tsm_forward_tap(tsm_engine *e, const void *clips, int32_t memkind, int32_t l
   TSM_HIP(e, hipMemcpyAsync(out, tap.ptr, (size_t)elems * sizeof(float),
                             memkind == TSM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
   TSM_HIP(e, hipStreamSynchronize(s));
+  return TSM_OK;
+}
+
+int tsm_set_layer_timing(tsm_engine *e, int32_t n_forwards, int32_t only_conv3x3) {
+  if (!e) return TSM_ERR_INVALID_ARG;
+  if (n_forwards < 0 || n_forwards > 64) return fail(e, TSM_ERR_INVALID_ARG, "n_forwards must be in [0, 64]");
+  e->timing_only3x3 = only_conv3x3 != 0;
+  for (auto &v : e->timing)
+    for (hipEvent_t ev : v)
+      if (ev) e->event_pool.push_back(ev);
+  e->timing.clear();
+  e->timing.reserve(64);
+  e->timing_left = n_forwards;
+  return TSM_OK;
+}
+
+int tsm_layer_times(tsm_engine *e, int32_t forward_index, float *ms_out, int32_t cap, int32_t *n_out) {
+  if (!e || !ms_out || !n_out) return TSM_ERR_INVALID_ARG;
+  if (forward_index < 0 || forward_index >= (int32_t)e->timing.size())
+    return fail(e, TSM_ERR_INVALID_ARG, "no timing recorded for that forward");
+  const std::vector<hipEvent_t> &ev = e->timing[forward_index];
+  const int n = (int)ev.size() / 2;
+  *n_out = n;
+  if (n > cap) return fail(e, TSM_ERR_CAPACITY, "ms_out too small");
+  for (int i = 0; i < n; ++i) {
+    ms_out[i] = -1.f;
+    if (!ev[2 * i] || !ev[2 * i + 1]) continue;
+    TSM_HIP(e, hipEventSynchronize(ev[2 * i + 1]));
+    TSM_HIP(e, hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]));
+  }
   return TSM_OK;
 }
 

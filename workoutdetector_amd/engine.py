@@ -168,6 +168,27 @@ class TsmEngine:
         dims = tuple(int(v) for v in shape)
         return buf[:int(np.prod(dims))].reshape(dims).copy()
 
+    # ---- per-launch timing (bench.py roofline) -------------------------------------------------------
+    def launch_names(self) -> List[str]:
+        """Names of the kernel launches of one forward, in launch order (matches tsm_layer_times)."""
+        names = ['pack_input', 'conv1', 'maxpool']
+        for li, nb in enumerate((3, 4, 6, 3), start=1):
+            for b in range(nb):
+                p = f'layer{li}.{b}'
+                names += ([p + '.downsample'] if b == 0 else []) + [p + '.conv1', p + '.conv2', p + '.conv3']
+        return names + ['head']
+
+    def set_layer_timing(self, n_forwards: int, only_conv3x3: bool = False) -> None:
+        _lib.check(self._lib.tsm_set_layer_timing(self._h, n_forwards, int(only_conv3x3)), self._h)
+
+    def layer_times_ms(self, forward_index: int) -> Dict[str, float]:
+        buf = (C.c_float * 80)()
+        n = C.c_int32()
+        _lib.check(self._lib.tsm_layer_times(self._h, forward_index, C.addressof(buf), 80, C.byref(n)), self._h)
+        names = self.launch_names()
+        assert n.value == len(names), (n.value, len(names))
+        return {k: float(buf[i]) for i, k in enumerate(names)}
+
     @property
     def last_forward_ms(self) -> float:
         return float(self._lib.tsm_last_forward_ms(self._h))
