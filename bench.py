@@ -10,8 +10,10 @@ every rank runs its own batch (weak scaling) and the only exchange is the RCCL a
 logits, which is inside the timed step.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant kernel is conv_igemm_f32<128,128,2,2,3,false,false>: the 3x3 convolutions of
-                layer2..layer4 (13 launches per forward, one third of the forward's time).  Every one of
+  roofline      the dominant kernel is the conv_igemm_f32<BM,BN,2,2,3,false,false> instantiation the engine's
+                autotuner picked for the 3x3 convolutions of layer2..layer4 (13 launches per forward, one
+                third of the forward's time; if the tuner split them over two tile shapes, the shape with
+                the larger total).  Every one of
                 those launches does the same algorithmic work, 115.6 MMAC/frame x 2 x frames (59.19 GFLOP
                 at batch 32); `achieved` = that / the launches' average duration, measured with HIP-event
                 pairs recorded around each launch on the launch stream during the timed steps
@@ -57,7 +59,7 @@ def host_cores():
     return min(n, int(os.environ.get('TSM_BENCH_CPU_THREADS', '16')))
 
 
-def measured_traffic(b, t, h, w):
+def measured_traffic(b, t, h, w, kernel):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json),
     only when they were collected on this exact configuration; bench.py cannot run PMC passes itself."""
     try:
@@ -66,6 +68,8 @@ def measured_traffic(b, t, h, w):
         return None
     c = d.get('config', {})
     if (c.get('clips_per_gpu'), c.get('num_segments'), c.get('height'), c.get('width')) != (b, t, h, w):
+        return None
+    if d.get('kernel') != kernel:
         return None
     return d.get('hbm_bytes_per_launch')
 
@@ -187,7 +191,14 @@ def main():
         dom_gflop = {2.0 * r['macs'] * frames / 1e9 for r in dom}
         assert len(dom_gflop) == 1, 'every 3x3 conv of ResNet-50 does the same work per frame'
         dom_gflop = dom_gflop.pop()
-        dom_ms = [d[r['name']] for d in per_launch for r in dom]
+        # The engine tunes the tile shape per layer, so the 3x3 convs may run on more than one
+        # instantiation of conv_igemm_f32: the dominant kernel is the instantiation with the most time.
+        tiles = eng.conv_tiles(B)
+        groups = {}
+        for r in dom:
+            groups.setdefault(tiles[r['name']], []).extend(d[r['name']] for d in per_launch)
+        dom_tile, dom_ms = max(groups.items(), key=lambda kv: sum(kv[1]))
+        dom_kernel = 'conv_igemm_f32<%s, 2, 2, 3, false, false>' % dom_tile.replace('x', ', ')
         dom_avg_ms = sum(dom_ms) / len(dom_ms)
         achieved = dom_gflop / dom_avg_ms
         line = {
@@ -201,9 +212,11 @@ def main():
                        'weights': 'seeded random init (no trained weights offline)',
                        'parallelism': f'clip-sharded x{world}, RCCL all-gather of logits' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': measured_traffic(B, T, H, W),
+                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         'traffic': measured_traffic(B, T, H, W, dom_kernel),
                          'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/traffic.json)',
-                         'kernel': 'conv_igemm_f32<128,128,2,2,3,false,false> (3x3 convs of layer2-4)',
+                         'kernel': dom_kernel + ' (3x3 convs of layer2-4, %d of 13 launches per forward)'
+                                   % (len(dom_ms) // len(per_launch)),
                          'gflop_per_launch': round(dom_gflop, 3), 'avg_launch_ms': round(dom_avg_ms, 4),
                          'launches_timed': len(dom_ms),
                          'peak_name': 'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), dense',

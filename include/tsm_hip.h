@@ -123,6 +123,12 @@ float tsm_last_forward_ms(tsm_engine *e);
 int tsm_set_layer_timing(tsm_engine *e, int32_t n_forwards, int32_t only_conv3x3);
 int tsm_layer_times(tsm_engine *e, int32_t forward_index, float *ms_out, int32_t cap, int32_t *n_out);
 
+/* Conv tile shape the engine's autotuner chose for each conv launch of an `n_clips` forward, in launch
+ * order (stem, then per block [downsample,] conv1, conv2, conv3): 1 = 128x128, 2 = 128x64, 3 = 64x64,
+ * 0 = not tuned (heuristic).  The first tsm_forward with a new n_clips times every valid shape per
+ * layer once (results are bit-identical across shapes); TSM_AUTOTUNE=0 in the environment disables it. */
+int tsm_conv_tiles(tsm_engine *e, int32_t n_clips, int32_t *tiles_out, int32_t cap, int32_t *n_out);
+
 /* Per-op entry points (device pointers; used by the parity tests and as building blocks) ----- */
 
 /* NHWC temporal shift, x/y: [n_frames, hw, c]; n_frames % n_segment == 0; c % (4*fold_div)==0 */

@@ -114,3 +114,23 @@ def test_error_behaviour(hip_lib, sd0, engine224):
         eng.load_state_dict(bad)
     assert ei.value.status == -5
     eng.close()
+
+
+def test_autotuned_tiles_are_bitwise_invariant(hip_lib, sd0, monkeypatch):
+    """The engine picks a conv tile shape per layer by timing; every shape accumulates each output in the
+    same k order, so logits must not depend on the choice (heuristic vs tuned vs each forced shape)."""
+    from workoutdetector_amd.engine import TsmEngine
+    x = make_input(21, 3, 8, 96, 96)
+    outs = {}
+    for name, env in [('tuned', {}), ('heuristic', {'TSM_AUTOTUNE': '0'}),
+                      ('64x64', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '64x64'})]:
+        for k in ('TSM_AUTOTUNE', 'TSM_CONV_TILE'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = TsmEngine(height=96, width=96, max_clips=3, state_dict=sd0)
+        outs[name] = eng.run(None, {'input': x})[0]
+        again = eng.run(None, {'input': x})[0]          # second call runs from the tile cache
+        assert np.array_equal(outs[name], again)
+        eng.close()
+    assert np.array_equal(outs['tuned'], outs['heuristic'])

@@ -31,7 +31,7 @@ class TsmError(RuntimeError):
 
 
 EXPORTS = ('tsm_abi_version', 'tsm_create', 'tsm_destroy', 'tsm_last_error', 'tsm_set_tensor', 'tsm_finalize',
-           'tsm_forward', 'tsm_forward_tap', 'tsm_last_forward_ms', 'tsm_set_layer_timing', 'tsm_layer_times', 'tsm_temporal_shift', 'tsm_conv_bn_act',
+           'tsm_forward', 'tsm_forward_tap', 'tsm_last_forward_ms', 'tsm_set_layer_timing', 'tsm_layer_times', 'tsm_conv_tiles', 'tsm_temporal_shift', 'tsm_conv_bn_act',
            'tsm_maxpool3x3s2', 'tsm_head')
 
 _lib: Optional[C.CDLL] = None
@@ -77,6 +77,8 @@ def load() -> C.CDLL:
     lib.tsm_set_layer_timing.argtypes = [vp, i32, i32]
     lib.tsm_layer_times.restype = C.c_int
     lib.tsm_layer_times.argtypes = [vp, i32, fp, i32, C.POINTER(i32)]
+    lib.tsm_conv_tiles.restype = C.c_int
+    lib.tsm_conv_tiles.argtypes = [vp, i32, C.POINTER(i32), i32, C.POINTER(i32)]
     lib.tsm_temporal_shift.restype = C.c_int
     lib.tsm_temporal_shift.argtypes = [fp, fp, i64, i32, i64, i32, i32, vp]
     lib.tsm_conv_bn_act.restype = C.c_int

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -91,6 +92,9 @@ struct tsm_engine {
   bool have_time = false;
   std::vector<void *> allocs;
   // per-launch timing (tsm_set_layer_timing): timing[f] = events of forward f, 2 per launch
+  // conv tile autotune: per frame count, one ConvTile per conv layer (0 = not tuned yet)
+  std::map<int, std::vector<int>> tile_cache;
+  bool autotune = true;
   int timing_left = 0;
   bool timing_only3x3 = false;
   std::vector<std::vector<hipEvent_t>> timing;
@@ -250,6 +254,48 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     return TSM_OK;
   };
 
+  // Tile shape per conv layer for this frame count: tuned on first use by timing every valid shape on
+  // the real launch (all shapes give bit-identical results: the k order per output does not depend on
+  // the tile), then cached.  TSM_AUTOTUNE=0 keeps the static heuristic.
+  std::vector<int> *tiles = nullptr;
+  bool tuning = false;
+  if (e->autotune && !stage) {
+    auto it = e->tile_cache.find(n);
+    if (it == e->tile_cache.end()) {
+      it = e->tile_cache.emplace(n, std::vector<int>(e->convs.size(), 0)).first;
+      tuning = true;
+    }
+    tiles = &it->second;
+  }
+  auto conv = [&](int idx, tsm::ConvParams p, int ks, bool is3x3) -> int {
+    if (tiles && !tuning) p.tile = (*tiles)[idx];
+    if (!tuning) {
+      TSM_LAUNCH_K(e, s, is3x3, tsm::launch_conv(p, ks, s));
+      return TSM_OK;
+    }
+    float best_ms = 0.f;
+    int best = 0;
+    for (int t = 1; t < tsm::kNumTiles; ++t) {
+      p.tile = t;
+      if (!tsm::conv_tile_valid(p, t)) continue;
+      float ms[3];
+      for (int rep = 0; rep < 3; ++rep) {
+        TSM_HIP(e, hipEventRecord(e->ev0, s));
+        TSM_HIP(e, tsm::launch_conv(p, ks, s));
+        TSM_HIP(e, hipEventRecord(e->ev1, s));
+        TSM_HIP(e, hipEventSynchronize(e->ev1));
+        TSM_HIP(e, hipEventElapsedTime(&ms[rep], e->ev0, e->ev1));
+      }
+      const float m = ms[1] < ms[2] ? ms[1] : ms[2];  // rep 0 warms the caches
+      if (best == 0 || m < best_ms) {
+        best = t;
+        best_ms = m;
+      }
+    }
+    (*tiles)[idx] = best;
+    return TSM_OK;
+  };
+
   TSM_LAUNCH(e, s, tsm::launch_pack_input(d_clips, e->d_in4, n, cfg.height, cfg.width,
                                           layout == TSM_LAYOUT_NTCHW ? 1 : 0, s));
   if (want("input")) return hit(e->d_in4, n, cfg.height, cfg.width, 4);
@@ -257,7 +303,8 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   float *cur = e->buf[0], *out = e->buf[1], *t1 = e->buf[2], *t2 = e->buf[3], *idb = e->buf[4];
   {
     tsm::ConvParams p = make_params(e->convs[0], e->d_in4, nullptr, t1, n, cfg.height, cfg.width, true, 0, 1);
-    TSM_LAUNCH(e, s, tsm::launch_conv(p, 7, s));
+    int rc0 = conv(0, p, 7, false);
+    if (rc0) return rc0;
     if (want("conv1")) return hit(t1, n, e->h1, e->w1, 64);
     TSM_LAUNCH(e, s, tsm::launch_maxpool3x3s2(t1, cur, n, e->h1, e->w1, 64, s));
     if (want("stem")) return hit(cur, n, e->hp, e->wp, 64);
@@ -272,17 +319,21 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     const float *identity = cur;
     if (blk.down >= 0) {
       tsm::ConvParams pd = make_params(e->convs[blk.down], cur, nullptr, idb, n, h, w, false, 0, 1);
-      TSM_LAUNCH(e, s, tsm::launch_conv(pd, 1, s));
+      int rcd = conv(blk.down, pd, 1, false);
+      if (rcd) return rcd;
       identity = idb;
     }
     tsm::ConvParams p1 = make_params(c1, cur, nullptr, t1, n, h, w, true, shiftT, cfg.shift_div);
-    TSM_LAUNCH(e, s, tsm::launch_conv(p1, 1, s));
+    int rc1 = conv(blk.conv1, p1, 1, false);
+    if (rc1) return rc1;
     if (want(name + ".conv1")) return hit(t1, n, h, w, c1.cout);
     tsm::ConvParams p2 = make_params(c2, t1, nullptr, t2, n, h, w, true, 0, 1);
-    TSM_LAUNCH_K(e, s, true, tsm::launch_conv(p2, 3, s));
+    int rc2 = conv(blk.conv2, p2, 3, true);
+    if (rc2) return rc2;
     if (want(name + ".conv2")) return hit(t2, n, ho, wo, c2.cout);
     tsm::ConvParams p3 = make_params(c3, t2, identity, out, n, ho, wo, true, 0, 1);
-    TSM_LAUNCH(e, s, tsm::launch_conv(p3, 1, s));
+    int rc3 = conv(blk.conv3, p3, 1, false);
+    if (rc3) return rc3;
     if (want(name)) return hit(out, n, ho, wo, c3.cout);
     std::swap(cur, out);
     h = ho; w = wo;
@@ -342,6 +393,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, TSM_ERR_INVALID_ARG, "bad device_id");
   tsm_engine *e = new tsm_engine();
   e->cfg = *cfg;
+  if (const char *at = getenv("TSM_AUTOTUNE")) e->autotune = atoi(at) != 0;
   build_topology(e);
   st = hipSetDevice(cfg->device_id);
   if (st == hipSuccess) st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -475,6 +527,15 @@ int tsm_forward(tsm_engine *e, const void *clips, int32_t memkind, int32_t layou
     e->timing.emplace_back();
     e->cur_timing = &e->timing.back();
   }
+  // A forward that still has to tune its tile shapes does so in a throw-away pass first (it uses the
+  // timing events and synchronises); the real pass below then runs from the cache.
+  if (e->autotune && e->tile_cache.find(n_clips * e->cfg.num_segments) == e->tile_cache.end()) {
+    std::vector<hipEvent_t> *saved = e->cur_timing;
+    e->cur_timing = nullptr;
+    rc = run_forward(e, d_clips, layout, n_clips, d_out, s, nullptr, nullptr);
+    e->cur_timing = saved;
+    if (rc) return rc;
+  }
   TSM_HIP(e, hipEventRecord(e->ev0, s));
   rc = run_forward(e, d_clips, layout, n_clips, d_out, s, nullptr, nullptr);
   e->cur_timing = nullptr;
@@ -542,6 +603,23 @@ int tsm_layer_times(tsm_engine *e, int32_t forward_index, float *ms_out, int32_t
     TSM_HIP(e, hipEventSynchronize(ev[2 * i + 1]));
     TSM_HIP(e, hipEventElapsedTime(&ms_out[i], ev[2 * i], ev[2 * i + 1]));
   }
+  return TSM_OK;
+}
+
+int tsm_conv_tiles(tsm_engine *e, int32_t n_clips, int32_t *tiles_out, int32_t cap, int32_t *n_out) {
+  if (!e || !tiles_out || !n_out) return TSM_ERR_INVALID_ARG;
+  // launch order: stem, then per block [downsample,] conv1, conv2, conv3
+  std::vector<int> order{0};
+  for (const Block &b : e->blocks) {
+    if (b.down >= 0) order.push_back(b.down);
+    order.push_back(b.conv1);
+    order.push_back(b.conv2);
+    order.push_back(b.conv3);
+  }
+  *n_out = (int32_t)order.size();
+  if ((int)order.size() > cap) return fail(e, TSM_ERR_CAPACITY, "tiles_out too small");
+  auto it = e->tile_cache.find(n_clips * e->cfg.num_segments);
+  for (size_t i = 0; i < order.size(); ++i) tiles_out[i] = it == e->tile_cache.end() ? 0 : it->second[order[i]];
   return TSM_OK;
 }
 

@@ -21,7 +21,12 @@ struct ConvParams {
   int T;     // > 0: temporal shift over T segments fused into the A loader (1x1, stride 1)
   int fold;  // C / shift_div
   int ntm, ntn;
+  int tile;  // 0 = heuristic, else a ConvTile chosen by the engine's autotuner
 };
+
+enum ConvTile { kTileAuto = 0, kTile128x128 = 1, kTile128x64 = 2, kTile64x64 = 3, kNumTiles = 4 };
+// Is `tile` usable for this problem (Cout divisibility)?
+bool conv_tile_valid(const ConvParams &p, int tile);
 
 // ks in {1, 3, 7}.  Returns hipSuccess or the launch error.
 hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s);

@@ -13,6 +13,9 @@
 // torchvision-0.13 ResNet-50 v1.5 Bottleneck for the conv stack.
 #include "tsm_kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace tsm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -369,14 +372,38 @@ void conv_tile_shape(const ConvParams &p, int *bm, int *bn) {
     BM = 64;
     BN = 64;
   }
+  // Tuning hook (tools/ sweeps only): TSM_CONV_TILE=128x64 | 64x64 | 128x128 forces a shape.
+  static const char *force = getenv("TSM_CONV_TILE");
+  if (force) {
+    int fm = 0, fn = 0;
+    if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm == 128 || fm == 64) && (fn == 128 || fn == 64) &&
+        !(fm == 64 && fn == 128) && p.Cout % fn == 0) {
+      BM = fm;
+      BN = fn;
+    }
+  }
   *bm = BM;
   *bn = BN;
+}
+
+bool conv_tile_valid(const ConvParams &p, int tile) {
+  switch (tile) {
+    case kTile128x128: return p.Cout % 128 == 0;
+    case kTile128x64:
+    case kTile64x64: return p.Cout % 64 == 0;
+    default: return false;
+  }
 }
 
 template <int KS, bool SHIFT, bool RES>
 static hipError_t launch_conv_ks(const ConvParams &p, hipStream_t s) {
   int bm, bn;
   conv_tile_shape(p, &bm, &bn);
+  if (p.tile != kTileAuto) {
+    if (!conv_tile_valid(p, p.tile)) return hipErrorInvalidValue;
+    bm = p.tile == kTile64x64 ? 64 : 128;
+    bn = p.tile == kTile128x128 ? 128 : 64;
+  }
   if (bm == 128 && bn == 128) return launch_conv_t<128, 128, 2, 2, KS, SHIFT, RES>(p, s);
   if (bm == 128 && bn == 64) return launch_conv_t<128, 64, 2, 2, KS, SHIFT, RES>(p, s);
   return launch_conv_t<64, 64, 2, 2, KS, SHIFT, RES>(p, s);
