@@ -59,8 +59,12 @@ typedef enum tsm_memkind { TSM_MEM_HOST = 0, TSM_MEM_DEVICE = 1 } tsm_memkind;
 /* Layout of the clip tensor handed to tsm_forward (T = num_segments). */
 typedef enum tsm_layout {
   TSM_LAYOUT_NTCHW = 0, /* float32 [B,T,3,H,W]  -- the reference's ONNX input            */
-  TSM_LAYOUT_NTHWC = 1  /* float32 [B,T,H,W,3]  -- decoder-native, skips the host permute */
+  TSM_LAYOUT_NTHWC = 1, /* float32 [B,T,H,W,3]  -- decoder-native, skips the host permute */
+  TSM_LAYOUT_NTHWC4 = 2 /* float32 [B,T,H,W,4]  -- what tsm_preprocess writes (4th channel 0);
+                           device memory only, consumed in place without a repack          */
 } tsm_layout;
+
+typedef enum tsm_pixel { TSM_PIXEL_U8 = 0, TSM_PIXEL_F32 = 1 } tsm_pixel;
 
 typedef enum tsm_dtype { TSM_DTYPE_F32 = 0 } tsm_dtype;
 
@@ -148,6 +152,17 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
 
 int tsm_maxpool3x3s2(const float *x, float *y, int32_t n, int32_t hi, int32_t wi, int32_t c,
                      void *stream);
+
+/* Fused test transform on the GPU (device pointers), the pre-step of the hot path:
+ *   build_test_transform(person_crop=False) = ConvertImageDtype -> Resize(resize) -> CenterCrop(crop)
+ *   -> Normalize(ImageNet)            workoutdetector/datasets/build.py:131-136
+ * frames: [n, h, w, 3] decoder layout, TSM_PIXEL_U8 or TSM_PIXEL_F32 (values 0..255).
+ * out:    out_layout TSM_LAYOUT_NTHWC4 -> [n, crop, crop, 4] (feed tsm_forward directly) or
+ *         TSM_LAYOUT_NTCHW -> [n, 3, crop, crop].
+ * scale_255 = 0 reproduces the reference's inference_dataset, which never divides by 255
+ * (utils/inference_count.py:412-414); 1 scales to [0,1] first. */
+int tsm_preprocess(const void *frames, int32_t pixel, int32_t n, int32_t h, int32_t w, float *out,
+                   int32_t out_layout, int32_t resize, int32_t crop, int32_t scale_255, void *stream);
 
 /* feat [n_clips*T, hw, c] NHWC -> logits [n_clips, num_class]; fc_w [num_class, c], fc_b. */
 int tsm_head(const float *feat, const float *fc_w, const float *fc_b, float *logits,

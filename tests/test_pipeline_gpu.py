@@ -63,7 +63,9 @@ def test_full_size_stream_properties(probe_engine, tmp_path):
     assert torch.equal(batched, single)
     for s in (0, 8 * 67, 8 * 134):                                            # incl. the zero-padded tail clip
         ref_style = ic.inference_video(eng, ic.make_clip(vid, s).cuda(), transform=tf)
-        np.testing.assert_array_equal(np.float32([v for _, v in ref_style]), batched[s // 8].numpy())
+        # reference-style path = torch transform + NCHW hand-over; batched path = fused HIP transform (K8):
+        # same math, different fp32 rounding of the bilinear weights
+        np.testing.assert_allclose(np.float32([v for _, v in ref_style]), batched[s // 8].numpy(), rtol=1e-5, atol=1e-4)
     states = scores_to_preds(batched.tolist())
     count, reps = pred_to_count(states, 8)
     assert count >= 20                                                        # 1080 / 36 = 30 brightness periods

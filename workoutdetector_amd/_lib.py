@@ -11,7 +11,8 @@ from .build import LIB_PATH
 ABI_VERSION = 1
 
 MEM_HOST, MEM_DEVICE = 0, 1
-LAYOUT_NTCHW, LAYOUT_NTHWC = 0, 1
+LAYOUT_NTCHW, LAYOUT_NTHWC, LAYOUT_NTHWC4 = 0, 1, 2
+PIXEL_U8, PIXEL_F32 = 0, 1
 DTYPE_F32 = 0
 
 STATUS_NAMES = {0: 'TSM_OK', -1: 'TSM_ERR_INVALID_ARG', -2: 'TSM_ERR_HIP', -3: 'TSM_ERR_NOT_FINALIZED',
@@ -32,7 +33,7 @@ class TsmError(RuntimeError):
 
 EXPORTS = ('tsm_abi_version', 'tsm_create', 'tsm_destroy', 'tsm_last_error', 'tsm_set_tensor', 'tsm_finalize',
            'tsm_forward', 'tsm_forward_tap', 'tsm_last_forward_ms', 'tsm_set_layer_timing', 'tsm_layer_times', 'tsm_conv_tiles', 'tsm_temporal_shift', 'tsm_conv_bn_act',
-           'tsm_maxpool3x3s2', 'tsm_head')
+           'tsm_maxpool3x3s2', 'tsm_head', 'tsm_preprocess')
 
 _lib: Optional[C.CDLL] = None
 
@@ -85,6 +86,8 @@ def load() -> C.CDLL:
     lib.tsm_conv_bn_act.argtypes = [fp] * 8 + [i32] * 10 + [vp]
     lib.tsm_maxpool3x3s2.restype = C.c_int
     lib.tsm_maxpool3x3s2.argtypes = [fp, fp, i32, i32, i32, i32, vp]
+    lib.tsm_preprocess.restype = C.c_int
+    lib.tsm_preprocess.argtypes = [vp, i32, i32, i32, i32, fp, i32, i32, i32, i32, vp]
     lib.tsm_head.restype = C.c_int
     lib.tsm_head.argtypes = [fp, fp, fp, fp, i32, i32, i32, i32, i32, vp]
     if lib.tsm_abi_version() != ABI_VERSION:

@@ -296,13 +296,18 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     return TSM_OK;
   };
 
-  TSM_LAUNCH(e, s, tsm::launch_pack_input(d_clips, e->d_in4, n, cfg.height, cfg.width,
-                                          layout == TSM_LAYOUT_NTCHW ? 1 : 0, s));
-  if (want("input")) return hit(e->d_in4, n, cfg.height, cfg.width, 4);
+  const float *in4 = e->d_in4;
+  if (layout == TSM_LAYOUT_NTHWC4) {
+    in4 = d_clips;  // already packed by tsm_preprocess: consumed in place
+  } else {
+    TSM_LAUNCH(e, s, tsm::launch_pack_input(d_clips, e->d_in4, n, cfg.height, cfg.width,
+                                            layout == TSM_LAYOUT_NTCHW ? 1 : 0, s));
+  }
+  if (want("input")) return hit(in4, n, cfg.height, cfg.width, 4);
 
   float *cur = e->buf[0], *out = e->buf[1], *t1 = e->buf[2], *t2 = e->buf[3], *idb = e->buf[4];
   {
-    tsm::ConvParams p = make_params(e->convs[0], e->d_in4, nullptr, t1, n, cfg.height, cfg.width, true, 0, 1);
+    tsm::ConvParams p = make_params(e->convs[0], in4, nullptr, t1, n, cfg.height, cfg.width, true, 0, 1);
     int rc0 = conv(0, p, 7, false);
     if (rc0) return rc0;
     if (want("conv1")) return hit(t1, n, e->h1, e->w1, 64);
@@ -358,7 +363,10 @@ int check_forward_args(tsm_engine *e, const void *clips, int memkind, int layout
   if (!e->finalized) return fail(e, TSM_ERR_NOT_FINALIZED, "tsm_finalize has not been called");
   if (!clips) return fail(e, TSM_ERR_INVALID_ARG, "clips is NULL");
   if (memkind != TSM_MEM_HOST && memkind != TSM_MEM_DEVICE) return fail(e, TSM_ERR_INVALID_ARG, "bad memkind");
-  if (layout != TSM_LAYOUT_NTCHW && layout != TSM_LAYOUT_NTHWC) return fail(e, TSM_ERR_INVALID_ARG, "bad layout");
+  if (layout != TSM_LAYOUT_NTCHW && layout != TSM_LAYOUT_NTHWC && layout != TSM_LAYOUT_NTHWC4)
+    return fail(e, TSM_ERR_INVALID_ARG, "bad layout");
+  if (layout == TSM_LAYOUT_NTHWC4 && memkind != TSM_MEM_DEVICE)
+    return fail(e, TSM_ERR_INVALID_ARG, "TSM_LAYOUT_NTHWC4 is a device-memory layout");
   if (n_clips <= 0) return fail(e, TSM_ERR_INVALID_ARG, "n_clips must be positive");
   if (n_clips > e->cfg.max_clips)
     return fail(e, TSM_ERR_CAPACITY, "n_clips " + std::to_string(n_clips) + " exceeds max_clips " +
@@ -702,6 +710,32 @@ int tsm_maxpool3x3s2(const float *x, float *y, int32_t n, int32_t hi, int32_t wi
   hipError_t st = tsm::launch_maxpool3x3s2(x, y, n, hi, wi, c, static_cast<hipStream_t>(stream));
   if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,
                                     std::string("maxpool: ") + hipGetErrorString(st));
+  return TSM_OK;
+}
+
+int tsm_preprocess(const void *frames, int32_t pixel, int32_t n, int32_t h, int32_t w, float *out,
+                   int32_t out_layout, int32_t resize, int32_t crop, int32_t scale_255, void *stream) {
+  if (!frames || !out || n <= 0 || h <= 0 || w <= 0 || resize <= 0 || crop <= 0)
+    return fail(nullptr, TSM_ERR_INVALID_ARG, "bad preprocess arguments");
+  if (pixel != TSM_PIXEL_U8 && pixel != TSM_PIXEL_F32) return fail(nullptr, TSM_ERR_INVALID_ARG, "bad pixel type");
+  if (out_layout != TSM_LAYOUT_NTHWC4 && out_layout != TSM_LAYOUT_NTCHW)
+    return fail(nullptr, TSM_ERR_INVALID_ARG, "out_layout must be NTHWC4 or NTCHW");
+  tsm::PreprocParams p{};
+  p.src = frames; p.dst = out; p.n = n; p.h = h; p.w = w;
+  // torchvision 0.13 Resize(int): short side -> resize, long side -> int(resize * long / short)
+  if (h <= w) { p.nh = resize; p.nw = (int)((double)resize * w / h); }
+  else { p.nh = (int)((double)resize * h / w); p.nw = resize; }
+  if (crop > p.nh || crop > p.nw) return fail(nullptr, TSM_ERR_INVALID_ARG, "crop larger than the resized frame");
+  // CenterCrop: int(round((dim - crop) / 2)) with Python's round-half-to-even
+  p.top = (int)std::nearbyint((p.nh - crop) / 2.0);
+  p.left = (int)std::nearbyint((p.nw - crop) / 2.0);
+  p.crop = crop;
+  p.src_is_u8 = pixel == TSM_PIXEL_U8;
+  p.out_nchw = out_layout == TSM_LAYOUT_NTCHW;
+  p.pre_scale = scale_255 ? 1.0f / 255.0f : 1.0f;
+  hipError_t st = tsm::launch_preprocess(p, static_cast<hipStream_t>(stream));
+  if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,
+                                    std::string("preprocess: ") + hipGetErrorString(st));
   return TSM_OK;
 }
 

@@ -35,6 +35,19 @@ void conv_tile_shape(const ConvParams &p, int *bm, int *bn);
 
 hipError_t launch_pack_input(const float *src, float *dst4, int64_t n_frames, int h, int w,
                              int nchw, hipStream_t s);
+// Fused test transform: [n,h,w,3] u8|f32 frames -> resize (short side -> `resize`, bilinear, no
+// antialias, align_corners=False) -> centre crop -> ImageNet normalise -> NHWC4 (out_nchw=0) or NCHW.
+struct PreprocParams {
+  const void *src;
+  float *dst;
+  int n, h, w;        // source frames
+  int nh, nw;         // resized size
+  int top, left, crop;
+  int src_is_u8, out_nchw;
+  float pre_scale;    // 1/255 when frames are to be scaled to [0,1] first, else 1
+};
+hipError_t launch_preprocess(const PreprocParams &p, hipStream_t s);
+
 hipError_t launch_maxpool3x3s2(const float *x, float *y, int n, int hi, int wi, int c,
                                hipStream_t s);
 hipError_t launch_temporal_shift(const float *x, float *y, int64_t n_frames, int n_segment,

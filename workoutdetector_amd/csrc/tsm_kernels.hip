@@ -459,6 +459,66 @@ hipError_t launch_pack_input(const float *src, float *dst4, int64_t n_frames, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// preprocess (K8): one thread per output pixel.  Bilinear sampling follows ATen's CPU kernel
+// (UpSampleBilinear2d): src = scale*(dst+0.5)-0.5 clamped at 0, scale = in/out,
+// out = h0*(w0*p00 + w1*p01) + h1*(w0*p10 + w1*p11); then (v*pre_scale - mean)/std.
+// datasets/build.py:131-136 of the reference (torchvision tensor transforms).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) preprocess_kernel(const PreprocParams p) {
+  const int64_t total = (int64_t)p.n * p.crop * p.crop;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float sh = (float)p.h / (float)p.nh, sw = (float)p.w / (float)p.nw;
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  const T *src = static_cast<const T *>(p.src);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cx = (int)(i % p.crop);
+    const int cy = (int)((i / p.crop) % p.crop);
+    const int64_t f = i / ((int64_t)p.crop * p.crop);
+    float fy = sh * ((float)(cy + p.top) + 0.5f) - 0.5f;
+    float fx = sw * ((float)(cx + p.left) + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+    const float h1 = fy - (float)y0, h0 = 1.f - h1, w1 = fx - (float)x0, w0 = 1.f - w1;
+    const T *b = src + f * (int64_t)p.h * p.w * 3;
+    const T *r0 = b + (int64_t)y0 * p.w * 3, *r1 = b + (int64_t)y1 * p.w * 3;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float p00 = (float)r0[x0 * 3 + c], p01 = (float)r0[x1 * 3 + c];
+      const float p10 = (float)r1[x0 * 3 + c], p11 = (float)r1[x1 * 3 + c];
+      const float t = h0 * (w0 * p00 + w1 * p01) + h1 * (w0 * p10 + w1 * p11);
+      v[c] = (t * p.pre_scale - mean[c]) / stdv[c];
+    }
+    v[3] = 0.f;
+    if (p.out_nchw) {
+      float *o = p.dst + f * 3 * (int64_t)p.crop * p.crop + (int64_t)cy * p.crop + cx;
+      o[0] = v[0];
+      o[(int64_t)p.crop * p.crop] = v[1];
+      o[2 * (int64_t)p.crop * p.crop] = v[2];
+    } else {
+      *reinterpret_cast<f32x4 *>(p.dst + i * 4) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+  }
+}
+
+hipError_t launch_preprocess(const PreprocParams &p, hipStream_t s) {
+  if (p.n <= 0 || p.h <= 0 || p.w <= 0 || p.crop <= 0 || p.top < 0 || p.left < 0 || p.top + p.crop > p.nh ||
+      p.left + p.crop > p.nw)
+    return hipErrorInvalidValue;
+  const int64_t total = (int64_t)p.n * p.crop * p.crop;
+  const int64_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+  if (p.src_is_u8)
+    hipLaunchKernelGGL(preprocess_kernel<unsigned char>, dim3(grid), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(preprocess_kernel<float>, dim3(grid), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // maxpool 3x3 stride 2 pad 1, NHWC; one thread per (output pixel, 4 channels).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float *__restrict__ x,

@@ -294,6 +294,29 @@ def conv_bn_act_nhwc(x, w, gamma, beta, mean, var, stride: int = 1, relu: bool =
     return y
 
 
+def preprocess_frames(frames, resize: int = 256, crop: int = 224, scale_255: bool = False, packed: bool = True):
+    """HIP test transform.  frames: CUDA uint8 or float32 [n,H,W,3] (decoder layout, values 0..255).
+    Returns float32 [n,crop,crop,4] (``packed``: feed ``forward_device(..., layout=LAYOUT_NTHWC4)``) or
+    [n,3,crop,crop]."""
+    import torch
+    frames = frames.contiguous()
+    if frames.dtype == torch.uint8:
+        pixel = _lib.PIXEL_U8
+    elif frames.dtype == torch.float32:
+        pixel = _lib.PIXEL_F32
+    else:
+        raise ValueError(f'frames must be uint8 or float32, got {frames.dtype}')
+    n, h, w, c = frames.shape
+    if c != 3 or not frames.is_cuda:
+        raise ValueError('frames must be a CUDA tensor [n,H,W,3]')
+    shape = (n, crop, crop, 4) if packed else (n, 3, crop, crop)
+    out = torch.empty(shape, dtype=torch.float32, device=frames.device)
+    _lib.check(_lib.load().tsm_preprocess(frames.data_ptr(), pixel, n, h, w, out.data_ptr(),
+                                          _lib.LAYOUT_NTHWC4 if packed else _lib.LAYOUT_NTCHW, resize, crop,
+                                          int(scale_255), _stream(frames)))
+    return out
+
+
 def maxpool3x3s2_nhwc(x):
     import torch
     x = x.contiguous()

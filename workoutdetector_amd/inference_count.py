@@ -10,9 +10,10 @@ Counterpart of workoutdetector/utils/inference_count.py for the video-model path
 
 What differs from the reference, on purpose:
   * ``model`` is anything with the onnxruntime duck type (``get_inputs()[0].name`` / ``run``); a
-    ``TsmEngine`` additionally gets the batched device path: all clips of a video are transformed on
-    the GPU once per *frame* (each even frame belongs to two half-overlapping windows; the transform
-    is per-frame, so this is bit-identical to transforming per clip) and pushed through the engine in
+    ``TsmEngine`` additionally gets the batched device path: the uint8 frames of a video go to the GPU
+    once, the fused HIP transform (``tsm_preprocess``: resize 256 / crop 224 / normalise -> NHWC4) runs
+    once per *frame* (each even frame belongs to two half-overlapping windows; the transform is
+    per-frame, so this equals transforming per clip) and the windows are pushed through the engine in
     batches instead of one synchronous ``run`` per clip.
   * videos come from a pluggable ``video_reader`` (the image has no H.264 decoder): ``.npy`` files of
     uint8 [F,H,W,3] frames are read natively, anything else goes to ``torchvision.io.read_video`` when
@@ -121,19 +122,30 @@ def video_clip_logits(model, video_thwc_u8: torch.Tensor, transform: TestTransfo
     f_lo = starts[lo] // CLIP_STRIDE
     f_hi = min((starts[hi - 1] + CLIP_SPAN) // CLIP_STRIDE, (total + 1) // CLIP_STRIDE)
     even = video_thwc_u8[0::CLIP_STRIDE][f_lo:f_hi]
-    if dev is not None:
-        even = even.to(dev, non_blocking=True)
-    frames = transform(even.permute(0, 3, 1, 2).to(torch.float32))            # [n_even, 3, 224, 224]
-    zero = transform(torch.zeros((1, 3) + tuple(video_thwc_u8.shape[1:3]), dtype=torch.float32,
-                                 device=frames.device))                        # the zero-padded tail frame
-    frames = torch.cat([frames, zero], dim=0)
+    hip_transform = dev is not None and isinstance(transform, TestTransform)
+    if hip_transform:
+        # HIP path: uint8 frames (+ one zero frame for the padded tail) -> fused resize/crop/normalise
+        # kernel -> NHWC4, which the engine consumes in place.
+        from .engine import preprocess_frames
+        from ._lib import LAYOUT_NTHWC4
+        even = torch.cat([even, torch.zeros((1,) + tuple(even.shape[1:]), dtype=even.dtype)]).to(dev, non_blocking=True)
+        frames = preprocess_frames(even, resize=transform.size, crop=transform.crop, scale_255=transform.scale_255)
+    else:
+        if dev is not None:
+            even = even.to(dev, non_blocking=True)
+        frames = transform(even.permute(0, 3, 1, 2).to(torch.float32))        # [n_even, 3, 224, 224]
+        zero = transform(torch.zeros((1, 3) + tuple(video_thwc_u8.shape[1:3]), dtype=torch.float32,
+                                     device=frames.device))                    # the zero-padded tail frame
+        frames = torch.cat([frames, zero], dim=0)
     zi = frames.shape[0] - 1
     idx = torch.tensor([[(s // CLIP_STRIDE + k - f_lo) if (s + CLIP_STRIDE * k) < total else zi
                          for k in range(NUM_SEGMENTS)] for s in starts[lo:hi]], device=frames.device)
     out = []
     for b in range(0, idx.shape[0], batch_clips):
-        clips = frames[idx[b:b + batch_clips]]                                # [b, 8, 3, 224, 224]
-        if dev is not None:
+        clips = frames[idx[b:b + batch_clips]]                                # [b, 8, 3, 224, 224] / [b, 8, 224, 224, 4]
+        if hip_transform:
+            out.append(model.forward_device(clips.contiguous(), layout=LAYOUT_NTHWC4).cpu())
+        elif dev is not None:
             out.append(model.forward_device(clips.contiguous()).cpu())
         else:
             name = model.get_inputs()[0].name
