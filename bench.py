@@ -105,6 +105,8 @@ def main():
     ap.add_argument('--segments', type=int, default=8)
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16x3'],
+                    help='f32: exact-fp32 MFMA; bf16x3: split-bf16 storage, 3 bf16 MFMAs per product')
     args = ap.parse_args()
 
     import numpy as np
@@ -135,7 +137,8 @@ def main():
 
     T, H, W, B = args.segments, args.size, args.size, args.batch
     sd = make_state_dict(0, 12)
-    eng = TsmEngine(num_class=12, num_segments=T, height=H, width=W, max_clips=B, device=local_rank, state_dict=sd)
+    eng = TsmEngine(num_class=12, num_segments=T, height=H, width=W, max_clips=B, device=local_rank, state_dict=sd,
+                    dtype=args.dtype)
     gen = torch.Generator(device='cuda').manual_seed(rank)
     clips = torch.randn(B, T, 3, H, W, device='cuda', generator=gen)
     logits = torch.empty(B, 12, device='cuda')

@@ -8,12 +8,13 @@ from typing import Optional
 
 from .build import LIB_PATH
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 MEM_HOST, MEM_DEVICE = 0, 1
-LAYOUT_NTCHW, LAYOUT_NTHWC, LAYOUT_NTHWC4 = 0, 1, 2
+LAYOUT_NTCHW, LAYOUT_NTHWC, LAYOUT_NTHWC4, LAYOUT_NTHWC8S = 0, 1, 2, 3
 PIXEL_U8, PIXEL_F32 = 0, 1
-DTYPE_F32 = 0
+DTYPE_F32, DTYPE_BF16X3 = 0, 1
+DTYPES = {'f32': DTYPE_F32, 'bf16x3': DTYPE_BF16X3}
 
 STATUS_NAMES = {0: 'TSM_OK', -1: 'TSM_ERR_INVALID_ARG', -2: 'TSM_ERR_HIP', -3: 'TSM_ERR_NOT_FINALIZED',
                 -4: 'TSM_ERR_MISSING_TENSOR', -5: 'TSM_ERR_SHAPE', -6: 'TSM_ERR_CAPACITY',
@@ -83,7 +84,7 @@ def load() -> C.CDLL:
     lib.tsm_temporal_shift.restype = C.c_int
     lib.tsm_temporal_shift.argtypes = [fp, fp, i64, i32, i64, i32, i32, vp]
     lib.tsm_conv_bn_act.restype = C.c_int
-    lib.tsm_conv_bn_act.argtypes = [fp] * 8 + [i32] * 10 + [vp]
+    lib.tsm_conv_bn_act.argtypes = [fp] * 8 + [i32] * 11 + [vp]
     lib.tsm_maxpool3x3s2.restype = C.c_int
     lib.tsm_maxpool3x3s2.argtypes = [fp, fp, i32, i32, i32, i32, vp]
     lib.tsm_preprocess.restype = C.c_int

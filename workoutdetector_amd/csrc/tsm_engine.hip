@@ -54,6 +54,32 @@ int ilog2(int v) {
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+uint16_t f2bf(float f) {  // round to nearest even, like v_cvt_pk_bf16_f32
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float bf2f(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+// In place: every group of 8 consecutive floats becomes [hi x8 | lo x8] bf16 (32 bytes, same size).
+void to_split(std::vector<float> *v) {
+  uint16_t g[16];
+  for (size_t i = 0; i + 8 <= v->size(); i += 8) {
+    for (int e = 0; e < 8; ++e) {
+      const float x = (*v)[i + e];
+      g[e] = f2bf(x);
+      g[8 + e] = f2bf(x - bf2f(g[e]));
+    }
+    std::memcpy(v->data() + i, g, 32);
+  }
+}
+
 // Fold BN into the conv and pack OIHW -> [Cout][Kp], K = (ky, kx, c) with c padded to cp.
 void fold_and_pack(const float *w, const float *gamma, const float *beta, const float *mean,
                    const float *var, int cout, int cin, int k, int cp, int kp, std::vector<float> *wp,
@@ -78,6 +104,8 @@ struct tsm_engine {
   std::string err;
   hipStream_t stream = nullptr;
   bool finalized = false;
+  int prec = tsm::kPrecF32;
+  float *d_tap = nullptr;     // fp32 staging for tsm_forward_tap on split-format engines
   std::map<std::string, HostTensor> tensors;
   std::vector<ConvLayer> convs;
   std::vector<Block> blocks;
@@ -122,8 +150,9 @@ void build_topology(tsm_engine *e) {
   ConvLayer stem;
   stem.wkey = "base_model.conv1.weight";
   stem.bnp = "base_model.bn1";
-  stem.cin = 3; stem.cout = 64; stem.k = 7; stem.stride = 2; stem.cp = 4;
-  stem.kp = round_up(7 * 7 * 4, 32);
+  stem.cin = 3; stem.cout = 64; stem.k = 7; stem.stride = 2;
+  stem.cp = e->prec == tsm::kPrecBf16x3 ? 8 : 4;  // split format works on 8-channel groups
+  stem.kp = round_up(7 * 7 * stem.cp, 32);
   e->convs.push_back(stem);
   int cin = 64;
   for (int li = 0; li < 4; ++li) {
@@ -191,8 +220,9 @@ int dev_alloc(tsm_engine *e, float **p, size_t elems) {
 }
 
 tsm::ConvParams make_params(const ConvLayer &c, const float *x, const float *res, float *y, int n, int hi,
-                            int wi, bool relu, int T, int shift_div) {
+                            int wi, bool relu, int T, int shift_div, int prec = tsm::kPrecF32) {
   tsm::ConvParams p{};
+  p.prec = prec;
   p.x = x; p.w = c.d_w; p.bias = c.d_b; p.res = res; p.y = y;
   p.N = n; p.Hi = hi; p.Wi = wi; p.C = c.cp; p.logC4 = ilog2(c.cp / 4);
   p.pad = c.k / 2; p.stride = c.stride;
@@ -296,22 +326,23 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     return TSM_OK;
   };
 
+  const int prec = e->prec;
   const float *in4 = e->d_in4;
-  if (layout == TSM_LAYOUT_NTHWC4) {
+  if (layout == TSM_LAYOUT_NTHWC4 || layout == TSM_LAYOUT_NTHWC8S) {
     in4 = d_clips;  // already packed by tsm_preprocess: consumed in place
   } else {
     TSM_LAUNCH(e, s, tsm::launch_pack_input(d_clips, e->d_in4, n, cfg.height, cfg.width,
-                                            layout == TSM_LAYOUT_NTCHW ? 1 : 0, s));
+                                            layout == TSM_LAYOUT_NTCHW ? 1 : 0, prec, s));
   }
-  if (want("input")) return hit(in4, n, cfg.height, cfg.width, 4);
+  if (want("input")) return hit(in4, n, cfg.height, cfg.width, e->convs[0].cp);
 
   float *cur = e->buf[0], *out = e->buf[1], *t1 = e->buf[2], *t2 = e->buf[3], *idb = e->buf[4];
   {
-    tsm::ConvParams p = make_params(e->convs[0], in4, nullptr, t1, n, cfg.height, cfg.width, true, 0, 1);
+    tsm::ConvParams p = make_params(e->convs[0], in4, nullptr, t1, n, cfg.height, cfg.width, true, 0, 1, prec);
     int rc0 = conv(0, p, 7, false);
     if (rc0) return rc0;
     if (want("conv1")) return hit(t1, n, e->h1, e->w1, 64);
-    TSM_LAUNCH(e, s, tsm::launch_maxpool3x3s2(t1, cur, n, e->h1, e->w1, 64, s));
+    TSM_LAUNCH(e, s, tsm::launch_maxpool3x3s2(t1, cur, n, e->h1, e->w1, 64, prec, s));
     if (want("stem")) return hit(cur, n, e->hp, e->wp, 64);
   }
   int h = e->hp, w = e->wp;
@@ -323,20 +354,20 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     const int ho = (h + 2 - 3) / blk.stride + 1, wo = (w + 2 - 3) / blk.stride + 1;
     const float *identity = cur;
     if (blk.down >= 0) {
-      tsm::ConvParams pd = make_params(e->convs[blk.down], cur, nullptr, idb, n, h, w, false, 0, 1);
+      tsm::ConvParams pd = make_params(e->convs[blk.down], cur, nullptr, idb, n, h, w, false, 0, 1, prec);
       int rcd = conv(blk.down, pd, 1, false);
       if (rcd) return rcd;
       identity = idb;
     }
-    tsm::ConvParams p1 = make_params(c1, cur, nullptr, t1, n, h, w, true, shiftT, cfg.shift_div);
+    tsm::ConvParams p1 = make_params(c1, cur, nullptr, t1, n, h, w, true, shiftT, cfg.shift_div, prec);
     int rc1 = conv(blk.conv1, p1, 1, false);
     if (rc1) return rc1;
     if (want(name + ".conv1")) return hit(t1, n, h, w, c1.cout);
-    tsm::ConvParams p2 = make_params(c2, t1, nullptr, t2, n, h, w, true, 0, 1);
+    tsm::ConvParams p2 = make_params(c2, t1, nullptr, t2, n, h, w, true, 0, 1, prec);
     int rc2 = conv(blk.conv2, p2, 3, true);
     if (rc2) return rc2;
     if (want(name + ".conv2")) return hit(t2, n, ho, wo, c2.cout);
-    tsm::ConvParams p3 = make_params(c3, t2, identity, out, n, ho, wo, true, 0, 1);
+    tsm::ConvParams p3 = make_params(c3, t2, identity, out, n, ho, wo, true, 0, 1, prec);
     int rc3 = conv(blk.conv3, p3, 1, false);
     if (rc3) return rc3;
     if (want(name)) return hit(out, n, ho, wo, c3.cout);
@@ -346,7 +377,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   }
   if (stage) return fail(e, TSM_ERR_INVALID_ARG, std::string("unknown stage: ") + stage);
   TSM_LAUNCH(e, s, tsm::launch_head(cur, e->d_fcw, e->d_fcb, e->d_pooled, d_logits, n_clips, T, h * w, 2048,
-                                    cfg.num_class, s));
+                                    cfg.num_class, prec, s));
   return TSM_OK;
 }
 
@@ -363,10 +394,12 @@ int check_forward_args(tsm_engine *e, const void *clips, int memkind, int layout
   if (!e->finalized) return fail(e, TSM_ERR_NOT_FINALIZED, "tsm_finalize has not been called");
   if (!clips) return fail(e, TSM_ERR_INVALID_ARG, "clips is NULL");
   if (memkind != TSM_MEM_HOST && memkind != TSM_MEM_DEVICE) return fail(e, TSM_ERR_INVALID_ARG, "bad memkind");
-  if (layout != TSM_LAYOUT_NTCHW && layout != TSM_LAYOUT_NTHWC && layout != TSM_LAYOUT_NTHWC4)
-    return fail(e, TSM_ERR_INVALID_ARG, "bad layout");
-  if (layout == TSM_LAYOUT_NTHWC4 && memkind != TSM_MEM_DEVICE)
-    return fail(e, TSM_ERR_INVALID_ARG, "TSM_LAYOUT_NTHWC4 is a device-memory layout");
+  if (layout < TSM_LAYOUT_NTCHW || layout > TSM_LAYOUT_NTHWC8S) return fail(e, TSM_ERR_INVALID_ARG, "bad layout");
+  if ((layout == TSM_LAYOUT_NTHWC4 || layout == TSM_LAYOUT_NTHWC8S) && memkind != TSM_MEM_DEVICE)
+    return fail(e, TSM_ERR_INVALID_ARG, "packed layouts (NTHWC4 / NTHWC8S) are device-memory layouts");
+  if ((layout == TSM_LAYOUT_NTHWC4 && e->prec != tsm::kPrecF32) ||
+      (layout == TSM_LAYOUT_NTHWC8S && e->prec != tsm::kPrecBf16x3))
+    return fail(e, TSM_ERR_INVALID_ARG, "packed layout does not match the engine dtype");
   if (n_clips <= 0) return fail(e, TSM_ERR_INVALID_ARG, "n_clips must be positive");
   if (n_clips > e->cfg.max_clips)
     return fail(e, TSM_ERR_CAPACITY, "n_clips " + std::to_string(n_clips) + " exceeds max_clips " +
@@ -393,7 +426,10 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
     return fail(nullptr, TSM_ERR_INVALID_ARG, "height/width must be >= 32");
   if (cfg->shift_div <= 0 || (64 % cfg->shift_div) != 0 || (64 / cfg->shift_div) % 4 != 0)
     return fail(nullptr, TSM_ERR_UNSUPPORTED, "shift_div must divide 64 with fold % 4 == 0 (8 or 16... )");
-  if (cfg->dtype != TSM_DTYPE_F32) return fail(nullptr, TSM_ERR_UNSUPPORTED, "only TSM_DTYPE_F32");
+  if (cfg->dtype != TSM_DTYPE_F32 && cfg->dtype != TSM_DTYPE_BF16X3)
+    return fail(nullptr, TSM_ERR_UNSUPPORTED, "dtype must be TSM_DTYPE_F32 or TSM_DTYPE_BF16X3");
+  if (cfg->dtype == TSM_DTYPE_BF16X3 && (64 / cfg->shift_div) % 8 != 0)
+    return fail(nullptr, TSM_ERR_UNSUPPORTED, "TSM_DTYPE_BF16X3 needs fold % 8 == 0 (shift_div <= 8)");
   int ndev = 0;
   hipError_t st = hipGetDeviceCount(&ndev);
   if (st != hipSuccess || ndev <= 0)
@@ -401,6 +437,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, TSM_ERR_INVALID_ARG, "bad device_id");
   tsm_engine *e = new tsm_engine();
   e->cfg = *cfg;
+  e->prec = cfg->dtype == TSM_DTYPE_BF16X3 ? tsm::kPrecBf16x3 : tsm::kPrecF32;
   if (const char *at = getenv("TSM_AUTOTUNE")) e->autotune = atoi(at) != 0;
   build_topology(e);
   st = hipSetDevice(cfg->device_id);
@@ -468,6 +505,7 @@ int tsm_finalize(tsm_engine *e) {
     std::vector<float> wp, bias;
     fold_and_pack(w->data.data(), g->data.data(), b->data.data(), m->data.data(), v->data.data(), c.cout,
                   c.cin, c.k, c.cp, c.kp, &wp, &bias);
+    if (e->prec == tsm::kPrecBf16x3) to_split(&wp);
     int rc = dev_alloc(e, &c.d_w, wp.size());
     if (rc) return rc;
     rc = dev_alloc(e, &c.d_b, bias.size());
@@ -503,7 +541,7 @@ int tsm_finalize(tsm_engine *e) {
   }
   rc = dev_alloc(e, &e->d_in, frames * 3 * cfg.height * cfg.width);
   if (rc) return rc;
-  rc = dev_alloc(e, &e->d_in4, frames * 4 * cfg.height * cfg.width);
+  rc = dev_alloc(e, &e->d_in4, frames * 8 * cfg.height * cfg.width);
   if (rc) return rc;
   rc = dev_alloc(e, &e->d_pooled, (size_t)cfg.max_clips * 2048);
   if (rc) return rc;
@@ -578,6 +616,17 @@ int tsm_forward_tap(tsm_engine *e, const void *clips, int32_t memkind, int32_t l
   const int64_t elems = tap.shape[0] * tap.shape[1] * tap.shape[2] * tap.shape[3];
   for (int i = 0; i < 4; ++i) out_shape[i] = tap.shape[i];
   if (elems > out_capacity) return fail(e, TSM_ERR_CAPACITY, "tap output buffer too small");
+  if (e->prec == tsm::kPrecBf16x3) {  // taps are reported as fp32 whatever the storage format
+    if (!e->d_tap) {
+      const size_t cap = e->buf_elems > (size_t)e->cfg.max_clips * e->cfg.num_segments * 8 * e->cfg.height * e->cfg.width
+                             ? e->buf_elems
+                             : (size_t)e->cfg.max_clips * e->cfg.num_segments * 8 * e->cfg.height * e->cfg.width;
+      rc = dev_alloc(e, &e->d_tap, cap);
+      if (rc) return rc;
+    }
+    TSM_HIP(e, tsm::launch_split_to_f32(tap.ptr, e->d_tap, elems / 8, s));
+    tap.ptr = e->d_tap;
+  }
   TSM_HIP(e, hipMemcpyAsync(out, tap.ptr, (size_t)elems * sizeof(float),
                             memkind == TSM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
   TSM_HIP(e, hipStreamSynchronize(s));
@@ -654,7 +703,10 @@ int tsm_temporal_shift(const float *x, float *y, int64_t n_frames, int32_t n_seg
 int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const float *beta, const float *mean,
                     const float *var, const float *residual, float *y, int32_t n, int32_t hi, int32_t wi,
                     int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t relu, int32_t shift_segments,
-                    int32_t fold_div, void *stream) {
+                    int32_t fold_div, int32_t dtype, void *stream) {
+  if (dtype != TSM_DTYPE_F32 && dtype != TSM_DTYPE_BF16X3) return fail(nullptr, TSM_ERR_UNSUPPORTED, "bad dtype");
+  const int prec = dtype == TSM_DTYPE_BF16X3 ? tsm::kPrecBf16x3 : tsm::kPrecF32;
+  const bool x3 = prec == tsm::kPrecBf16x3;
   if (!x || !w || !gamma || !beta || !mean || !var || !y) return fail(nullptr, TSM_ERR_INVALID_ARG, "NULL pointer");
   if (k != 1 && k != 3 && k != 7) return fail(nullptr, TSM_ERR_UNSUPPORTED, "k must be 1, 3 or 7");
   if (stride != 1 && stride != 2) return fail(nullptr, TSM_ERR_UNSUPPORTED, "stride must be 1 or 2");
@@ -665,7 +717,7 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
   hipStream_t s = static_cast<hipStream_t>(stream);
   ConvLayer c;
   c.cin = cin; c.cout = cout; c.k = k; c.stride = stride;
-  c.cp = stem ? 4 : cin;
+  c.cp = stem ? (x3 ? 8 : 4) : cin;
   c.kp = round_up(k * k * c.cp, 32);
   std::vector<float> hw_((size_t)cout * cin * k * k), hg(cout), hb(cout), hm(cout), hv(cout), wp, bias;
 #define TSM_HIP0(call)                                                                              \
@@ -680,24 +732,47 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
   TSM_HIP0(hipMemcpy(hm.data(), mean, cout * sizeof(float), hipMemcpyDeviceToHost));
   TSM_HIP0(hipMemcpy(hv.data(), var, cout * sizeof(float), hipMemcpyDeviceToHost));
   fold_and_pack(hw_.data(), hg.data(), hb.data(), hm.data(), hv.data(), cout, cin, k, c.cp, c.kp, &wp, &bias);
-  float *d_w = nullptr, *d_b = nullptr, *d_x4 = nullptr;
+  if (x3) to_split(&wp);
+  float *d_w = nullptr, *d_b = nullptr, *d_x4 = nullptr, *d_xs = nullptr, *d_rs = nullptr, *d_ys = nullptr;
   TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_w), wp.size() * sizeof(float)));
   TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_b), bias.size() * sizeof(float)));
   TSM_HIP0(hipMemcpy(d_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
   TSM_HIP0(hipMemcpy(d_b, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
   c.d_w = d_w; c.d_b = d_b;
   const float *xin = x;
-  if (stem) {  // NHWC3 -> NHWC4
-    TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_x4), (size_t)n * hi * wi * 4 * sizeof(float)));
-    TSM_HIP0(tsm::launch_pack_input(x, d_x4, n, hi, wi, 0, s));
+  const float *rin = residual;
+  float *yout = y;
+  const int pad_ = k / 2;
+  const size_t out_elems = (size_t)n * ((hi + 2 * pad_ - k) / stride + 1) * ((wi + 2 * pad_ - k) / stride + 1) * cout;
+  if (stem) {  // NHWC3 -> NHWC4 fp32 / NHWC8 split
+    TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_x4), (size_t)n * hi * wi * 8 * sizeof(float)));
+    TSM_HIP0(tsm::launch_pack_input(x, d_x4, n, hi, wi, 0, prec, s));
     xin = d_x4;
+  } else if (x3) {
+    TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_xs), (size_t)n * hi * wi * cin * sizeof(float)));
+    TSM_HIP0(tsm::launch_f32_to_split(x, d_xs, (int64_t)n * hi * wi * cin / 8, s));
+    xin = d_xs;
   }
-  tsm::ConvParams p = make_params(c, xin, residual, y, n, hi, wi, relu != 0, shift_segments, fold_div > 0 ? fold_div : 1);
+  if (x3) {
+    TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_ys), out_elems * sizeof(float)));
+    yout = d_ys;
+    if (residual) {
+      TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_rs), out_elems * sizeof(float)));
+      TSM_HIP0(tsm::launch_f32_to_split(residual, d_rs, (int64_t)out_elems / 8, s));
+      rin = d_rs;
+    }
+  }
+  tsm::ConvParams p = make_params(c, xin, rin, yout, n, hi, wi, relu != 0, shift_segments,
+                                  fold_div > 0 ? fold_div : 1, prec);
   hipError_t st = tsm::launch_conv(p, k, s);
+  if (st == hipSuccess && x3) st = tsm::launch_split_to_f32(d_ys, y, (int64_t)out_elems / 8, s);
   hipError_t st2 = hipStreamSynchronize(s);
   (void)hipFree(d_w);
   (void)hipFree(d_b);
   if (d_x4) (void)hipFree(d_x4);
+  if (d_xs) (void)hipFree(d_xs);
+  if (d_rs) (void)hipFree(d_rs);
+  if (d_ys) (void)hipFree(d_ys);
   if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,
                                     std::string("launch_conv: ") + hipGetErrorString(st));
   if (st2 != hipSuccess) return fail(nullptr, TSM_ERR_HIP, std::string("conv sync: ") + hipGetErrorString(st2));
@@ -707,7 +782,7 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
 
 int tsm_maxpool3x3s2(const float *x, float *y, int32_t n, int32_t hi, int32_t wi, int32_t c, void *stream) {
   if (!x || !y || n <= 0 || hi <= 0 || wi <= 0) return TSM_ERR_INVALID_ARG;
-  hipError_t st = tsm::launch_maxpool3x3s2(x, y, n, hi, wi, c, static_cast<hipStream_t>(stream));
+  hipError_t st = tsm::launch_maxpool3x3s2(x, y, n, hi, wi, c, tsm::kPrecF32, static_cast<hipStream_t>(stream));
   if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,
                                     std::string("maxpool: ") + hipGetErrorString(st));
   return TSM_OK;
@@ -718,8 +793,8 @@ int tsm_preprocess(const void *frames, int32_t pixel, int32_t n, int32_t h, int3
   if (!frames || !out || n <= 0 || h <= 0 || w <= 0 || resize <= 0 || crop <= 0)
     return fail(nullptr, TSM_ERR_INVALID_ARG, "bad preprocess arguments");
   if (pixel != TSM_PIXEL_U8 && pixel != TSM_PIXEL_F32) return fail(nullptr, TSM_ERR_INVALID_ARG, "bad pixel type");
-  if (out_layout != TSM_LAYOUT_NTHWC4 && out_layout != TSM_LAYOUT_NTCHW)
-    return fail(nullptr, TSM_ERR_INVALID_ARG, "out_layout must be NTHWC4 or NTCHW");
+  if (out_layout != TSM_LAYOUT_NTHWC4 && out_layout != TSM_LAYOUT_NTCHW && out_layout != TSM_LAYOUT_NTHWC8S)
+    return fail(nullptr, TSM_ERR_INVALID_ARG, "out_layout must be NTHWC4, NTHWC8S or NTCHW");
   tsm::PreprocParams p{};
   p.src = frames; p.dst = out; p.n = n; p.h = h; p.w = w;
   // torchvision 0.13 Resize(int): short side -> resize, long side -> int(resize * long / short)
@@ -731,7 +806,7 @@ int tsm_preprocess(const void *frames, int32_t pixel, int32_t n, int32_t h, int3
   p.left = (int)std::nearbyint((p.nw - crop) / 2.0);
   p.crop = crop;
   p.src_is_u8 = pixel == TSM_PIXEL_U8;
-  p.out_nchw = out_layout == TSM_LAYOUT_NTCHW;
+  p.out_mode = out_layout == TSM_LAYOUT_NTCHW ? 1 : (out_layout == TSM_LAYOUT_NTHWC8S ? 2 : 0);
   p.pre_scale = scale_255 ? 1.0f / 255.0f : 1.0f;
   hipError_t st = tsm::launch_preprocess(p, static_cast<hipStream_t>(stream));
   if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,
@@ -747,7 +822,7 @@ int tsm_head(const float *feat, const float *fc_w, const float *fc_b, float *log
   float *pooled = nullptr;
   hipError_t st = hipMalloc(reinterpret_cast<void **>(&pooled), (size_t)n_clips * c * sizeof(float));
   if (st != hipSuccess) return fail(nullptr, TSM_ERR_HIP, std::string("head scratch: ") + hipGetErrorString(st));
-  st = tsm::launch_head(feat, fc_w, fc_b, pooled, logits, n_clips, n_segment, hw, c, num_class, s);
+  st = tsm::launch_head(feat, fc_w, fc_b, pooled, logits, n_clips, n_segment, hw, c, num_class, tsm::kPrecF32, s);
   hipError_t st2 = hipStreamSynchronize(s);
   (void)hipFree(pooled);
   if (st != hipSuccess || st2 != hipSuccess)

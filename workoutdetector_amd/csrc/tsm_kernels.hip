@@ -50,13 +50,39 @@ constexpr int kBK = 32;
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned kInvalid = 0x80000000u;  // >= num_records of every descriptor below
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// split-bf16 helpers.  A 32-byte group is [hi x8 | lo x8]; word w of a half holds elements 2w (low 16
+// bits) and 2w+1 (high 16 bits).
+__device__ __forceinline__ float split_elem(u32x4 half8, int e) {
+  const unsigned w = half8[e >> 1];
+  return __builtin_bit_cast(float, (e & 1) ? (w & 0xFFFF0000u) : (w << 16));
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned *hi, unsigned *lo) {
+  const bf16x2 h = {(__bf16)x0, (__bf16)x1};  // v_cvt_pk_bf16_f32, round to nearest even
+  const unsigned hw = __builtin_bit_cast(unsigned, h);
+  const float r0 = x0 - __builtin_bit_cast(float, hw << 16);
+  const float r1 = x1 - __builtin_bit_cast(float, hw & 0xFFFF0000u);
+  const bf16x2 l = {(__bf16)r0, (__bf16)r1};
+  *hi = hw;
+  *lo = __builtin_bit_cast(unsigned, l);
+}
+
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
 }
 
-template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES>
-__global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
+// PREC selects the arithmetic:
+//   kPrecF32     activations/weights fp32, v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain)
+//   kPrecBf16x3  "split-bf16": every value is stored as hi = bf16(x), lo = bf16(x - hi), 8 channels per
+//                32-byte group [hi x8 | lo x8] (same 4 bytes per element, same byte offsets as fp32, so the
+//                loader is shared).  a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32
+//                accumulation: relative error ~2^-17 per product, three MFMAs at 16x the fp32-MFMA rate.
+template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC>
+__global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  constexpr bool X3 = PREC == kPrecBf16x3;
   static_assert(!SHIFT || KS == 1, "the temporal shift is fused into 1x1 convs only");
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -160,7 +186,7 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
       // channels [0,fold) <- frame t+1, [fold,2fold) <- frame t-1, rest <- frame t.  Kept as AND/OR
       // masks: a three-way select over the per-row offset arrays is turned into a scratch-memory
       // table by the compiler, which serialises the loader behind vmcnt(0).
-      const int c = kt * kBK + chunk * 4;
+      const int c = kt * kBK + (X3 ? (chunk >> 1) * 8 : chunk * 4);
       k.mp = 0u - (unsigned)(c < p.fold);
       k.mm = (0u - (unsigned)(c < 2 * p.fold)) & ~k.mp;
       k.m0 = ~(k.mp | k.mm);
@@ -185,12 +211,14 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
       } else if (KS == 3) {
         ra[pp] = buf_load4(rsrcA, (((a_mask[pp] >> k.tap) & 1u) ? a_off[pp] + (unsigned)k.tap_off : kInvalid) | k.dead, 0);
       } else {
-        // stem: C = 4, one tap per 16-B chunk, taps 49..55 are K padding
-        const int tap = kt * 8 + chunk;
+        // stem: fp32 C = 4 -> one tap per 16-B chunk; split C = 8 -> one tap per chunk pair (hi, lo);
+        // taps >= 49 are K padding
+        const int tap = X3 ? (kt * 8 + chunk) >> 1 : kt * 8 + chunk;
         const int ky = tap / 7, kx = tap - ky * 7;
         const int iy = a_iy[pp] + ky, ix = a_ix[pp] + kx;
         const bool ok = tap < 49 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        ra[pp] = buf_load4(rsrcA, (ok ? a_off[pp] + (unsigned)((iy * p.Wi + ix) * 16) : kInvalid) | k.dead, 0);
+        const unsigned pix = X3 ? (unsigned)((iy * p.Wi + ix) * 32 + (chunk & 1) * 16) : (unsigned)((iy * p.Wi + ix) * 16);
+        ra[pp] = buf_load4(rsrcA, (ok ? a_off[pp] + pix : kInvalid) | k.dead, 0);
       }
     } else {
       const int pp = item - APASS;
@@ -258,14 +286,67 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
   };
   (void)no_inject;
 
+  // ---- split-bf16 fragments: an LDS row is 4 channel groups of [hi x8 | lo x8]; v_mfma_f32_32x32x16_bf16
+  // takes A[row][k = 8*(lane>>5) + j], so k16-group q reads channel group g = 2q + (lane>>5).
+  u32x4 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+  auto frag_load_x3 = [&](int buf, int qg, int set) {
+    const float *As = smem + buf * (BM + BN) * kLds + (wm * WTM + l31) * kLds + (2 * qg + half) * 8;
+    const float *Bs = smem + buf * (BM + BN) * kLds + BM * kLds + (wn * WTN + l31) * kLds + (2 * qg + half) * 8;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      ah[set][i] = *reinterpret_cast<const u32x4 *>(As + i * 32 * kLds);
+      al[set][i] = *reinterpret_cast<const u32x4 *>(As + i * 32 * kLds + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bh[set][j] = *reinterpret_cast<const u32x4 *>(Bs + j * 32 * kLds);
+      bl[set][j] = *reinterpret_cast<const u32x4 *>(Bs + j * 32 * kLds + 4);
+    }
+  };
+  constexpr int NMFMA3 = 3 * TM * TN;
+  auto mfma_x3 = [&](int set, int nitems, auto &&inject) {
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const bf16x8 a = __builtin_bit_cast(bf16x8, t == 2 ? al[set][i] : ah[set][i]);
+          const bf16x8 b = __builtin_bit_cast(bf16x8, t == 1 ? bl[set][j] : bh[set][j]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+          ++cnt;
+          const int done = (cnt * nitems) / NMFMA3, before = ((cnt - 1) * nitems) / NMFMA3;
+#pragma unroll
+          for (int it = before; it < done; ++it) {
+            inject(it);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+  };
+
   // Residual tile: fetched before the K loop (it does not depend on it) in the epilogue's own
   // row-major 16-B mapping, so its HBM latency hides under the MFMAs.  Rows past M read as zeros.
-  constexpr int TPR = BN / 4;          // threads per output row
+  constexpr int EW = X3 ? 8 : 4;       // channels per thread per pass (split: one 32-byte group)
+  constexpr int TPR = BN / EW;         // threads per output row
   constexpr int RPP = 256 / TPR;       // rows per pass
   constexpr int EPASS = BM / RPP;
-  const int ecol = (tid % TPR) * 4, erow = tid / TPR;
-  f32x4 rres[RES ? EPASS : 1];
-  if (RES) {
+  const int ecol = (tid % TPR) * EW, erow = tid / TPR;
+  f32x4 rres[(RES && !X3) ? EPASS : 1];
+  u32x4 rres_h[(RES && X3) ? EPASS : 1], rres_l[(RES && X3) ? EPASS : 1];
+  if (RES && X3) {
+    const size_t r_bytes = ((size_t)p.M - m0) * p.Cout * 4;
+    const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.res + (size_t)m0 * p.Cout), 0,
+        (int)(r_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : r_bytes), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < EPASS; ++k) {
+      const unsigned o = (unsigned)(((erow + k * RPP) * p.Cout + n0 + ecol) * 4);
+      rres_h[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)o, 0, 0);
+      rres_l[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)(o + 16), 0, 0);
+    }
+  }
+  if (RES && !X3) {
     const size_t r_bytes = ((size_t)p.M - m0) * p.Cout * 4;
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.res + (size_t)m0 * p.Cout), 0,
@@ -299,23 +380,46 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
     for (int it = 0; it < NITEMS; ++it) gload_item(k1, 1, it);
   }
   __syncthreads();
-  frag_load(0, 0, 0);
-  frag_load(0, 1, 1);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const KStep k2 = kstep(kt + 2, nk);
-    mfma_plain(0);
-    frag_load(cur, 2, 0);
-    mfma_group(1, [&](int it) { lstore_item(cur ^ 1, it); });
-    frag_load(cur, 3, 1);
-    mfma_group(0, [&](int it) { gload_item(k2, kt + 2, it); });
-    __syncthreads();
-    frag_load(cur ^ 1, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_plain(1);
-    __builtin_amdgcn_sched_barrier(0);
-    frag_load(cur ^ 1, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!X3) {
+    frag_load(0, 0, 0);
+    frag_load(0, 1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const KStep k2 = kstep(kt + 2, nk);
+      mfma_plain(0);
+      frag_load(cur, 2, 0);
+      mfma_group(1, [&](int it) { lstore_item(cur ^ 1, it); });
+      frag_load(cur, 3, 1);
+      mfma_group(0, [&](int it) { gload_item(k2, kt + 2, it); });
+      __syncthreads();
+      frag_load(cur ^ 1, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_plain(1);
+      __builtin_amdgcn_sched_barrier(0);
+      frag_load(cur ^ 1, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // split-bf16: a K-step is two k16-groups of 3*TM*TN MFMAs (32 cycles each).  Group 0 carries the
+    // ds_writes of tile kt+1 and the buffer loads of tile kt+2; group 1 is issued after the barrier and
+    // covers the LDS latency of the next tile's fragments.  Same buffer/barrier reasoning as above.
+    frag_load_x3(0, 0, 0);
+    frag_load_x3(0, 1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const KStep k2 = kstep(kt + 2, nk);
+      mfma_x3(0, 2 * NITEMS, [&](int it) {
+        if (it < NITEMS) lstore_item(cur ^ 1, it);
+        else gload_item(k2, kt + 2, it - NITEMS);
+      });
+      __syncthreads();
+      frag_load_x3(cur ^ 1, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_x3(1, 0, [](int) {});
+      __builtin_amdgcn_sched_barrier(0);
+      frag_load_x3(cur ^ 1, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
@@ -336,20 +440,49 @@ __global__ void __launch_bounds__(256) conv_igemm_f32(const ConvParams p) {
   const size_t y_bytes = ((size_t)p.M - m0) * p.Cout * 4;
   const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
       p.y + (size_t)m0 * p.Cout, 0, (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
-  const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
   const float floor_ = p.relu ? 0.f : -INFINITY;  // ReLU as a branch-free clamp
+  if constexpr (!X3) {
+    const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
 #pragma unroll
-  for (int k = 0; k < EPASS; ++k) {
-    const int rr = erow + k * RPP;
-    f32x4 v = *reinterpret_cast<const f32x4 *>(Cs + rr * CLD + ecol);
-    v += bias;
-    if (RES) v += rres[k];
-    v[0] = fmaxf(v[0], floor_);
-    v[1] = fmaxf(v[1], floor_);
-    v[2] = fmaxf(v[2], floor_);
-    v[3] = fmaxf(v[3], floor_);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcY,
-                                           (int)((rr * p.Cout + n0 + ecol) * 4), 0, 0);
+    for (int k = 0; k < EPASS; ++k) {
+      const int rr = erow + k * RPP;
+      f32x4 v = *reinterpret_cast<const f32x4 *>(Cs + rr * CLD + ecol);
+      v += bias;
+      if (RES) v += rres[k];
+      v[0] = fmaxf(v[0], floor_);
+      v[1] = fmaxf(v[1], floor_);
+      v[2] = fmaxf(v[2], floor_);
+      v[3] = fmaxf(v[3], floor_);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcY,
+                                             (int)((rr * p.Cout + n0 + ecol) * 4), 0, 0);
+    }
+  } else {
+    const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
+    const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol + 4);
+#pragma unroll
+    for (int k = 0; k < EPASS; ++k) {
+      const int rr = erow + k * RPP;
+      const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cs + rr * CLD + ecol);
+      const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cs + rr * CLD + ecol + 4);
+      float v[8] = {c0[0] + bias0[0], c0[1] + bias0[1], c0[2] + bias0[2], c0[3] + bias0[3],
+                    c1[0] + bias1[0], c1[1] + bias1[1], c1[2] + bias1[2], c1[3] + bias1[3]};
+      if (RES) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += split_elem(rres_h[k], e) + split_elem(rres_l[k], e);
+      }
+      u32x4 oh, ol;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float x0 = fmaxf(v[2 * w], floor_), x1 = fmaxf(v[2 * w + 1], floor_);
+        unsigned hw, lw;
+        split_pair(x0, x1, &hw, &lw);
+        oh[w] = hw;
+        ol[w] = lw;
+      }
+      const int o = (rr * p.Cout + n0 + ecol) * 4;
+      __builtin_amdgcn_raw_buffer_store_b128(oh, rsrcY, o, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ol, rsrcY, o + 16, 0, 0);
+    }
   }
 }
 
@@ -358,7 +491,10 @@ static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
   p.ntm = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   const dim3 grid((unsigned)(p.ntm * p.ntn));
-  hipLaunchKernelGGL((conv_igemm_f32<BM, BN, WGM, WGN, KS, SHIFT, RES>), grid, dim3(256), 0, s, p);
+  if (p.prec == kPrecBf16x3)
+    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16x3>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32>), grid, dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
@@ -414,6 +550,8 @@ hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s) {
   if ((1 << p.logC4) * 4 != p.C) return hipErrorInvalidValue;
   if (ks != 7 && p.C % kBK != 0) return hipErrorInvalidValue;
   if (p.T > 0 && (ks != 1 || p.stride != 1 || p.N % p.T != 0 || p.fold % 4 != 0)) return hipErrorInvalidValue;
+  if (p.prec != kPrecF32 && p.prec != kPrecBf16x3) return hipErrorInvalidValue;
+  if (p.prec == kPrecBf16x3 && ((p.T > 0 && p.fold % 8 != 0) || (ks == 7 && p.C != 8))) return hipErrorInvalidValue;
   // 32-bit byte offsets inside a workgroup's rebased window: a tile touches at most
   // BM/(Ho*Wo) + 4 input frames.
   const double frames = 128.0 / ((double)p.Ho * p.Wo) + 4.0;
@@ -431,6 +569,7 @@ hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // pack_input: one thread per pixel; planar reads are coalesced along W, the write is one 16-B store.
 // ---------------------------------------------------------------------------------------------
+template <bool X3>
 __global__ void __launch_bounds__(256) pack_input_kernel(const float *__restrict__ src,
                                                          float *__restrict__ dst, int64_t n_pix_total,
                                                          int64_t hw, int nchw) {
@@ -445,16 +584,73 @@ __global__ void __launch_bounds__(256) pack_input_kernel(const float *__restrict
       const float *b = src + i * 3;
       v = {b[0], b[1], b[2], 0.f};
     }
-    *reinterpret_cast<f32x4 *>(dst + i * 4) = v;
+    if (X3) {  // NHWC8 split: [hi x8 | lo x8], channels 3..7 are zero
+      u32x4 oh = {0u, 0u, 0u, 0u}, ol = {0u, 0u, 0u, 0u};
+      unsigned h0, l0, h1, l1;
+      split_pair(v[0], v[1], &h0, &l0);
+      split_pair(v[2], 0.f, &h1, &l1);
+      oh[0] = h0; oh[1] = h1; ol[0] = l0; ol[1] = l1;
+      *reinterpret_cast<u32x4 *>(dst + i * 8) = oh;
+      *reinterpret_cast<u32x4 *>(dst + i * 8 + 4) = ol;
+    } else {
+      *reinterpret_cast<f32x4 *>(dst + i * 4) = v;
+    }
   }
 }
 
-hipError_t launch_pack_input(const float *src, float *dst4, int64_t n_frames, int h, int w, int nchw,
+hipError_t launch_pack_input(const float *src, float *dst, int64_t n_frames, int h, int w, int nchw, int prec,
                              hipStream_t s) {
   const int64_t hw = (int64_t)h * w, total = n_frames * hw;
   const int64_t blocks = (total + 255) / 256;
   const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
-  hipLaunchKernelGGL(pack_input_kernel, dim3(grid), dim3(256), 0, s, src, dst4, total, hw, nchw);
+  if (prec == kPrecBf16x3)
+    hipLaunchKernelGGL(pack_input_kernel<true>, dim3(grid), dim3(256), 0, s, src, dst, total, hw, nchw);
+  else
+    hipLaunchKernelGGL(pack_input_kernel<false>, dim3(grid), dim3(256), 0, s, src, dst, total, hw, nchw);
+  return hipGetLastError();
+}
+
+// fp32 <-> split-bf16, one thread per 8-channel group
+__global__ void __launch_bounds__(256) f32_to_split_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                           int64_t n_groups) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_groups; i += stride) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(x + i * 8), b = *reinterpret_cast<const f32x4 *>(x + i * 8 + 4);
+    u32x4 oh, ol;
+    unsigned h, l;
+    split_pair(a[0], a[1], &h, &l); oh[0] = h; ol[0] = l;
+    split_pair(a[2], a[3], &h, &l); oh[1] = h; ol[1] = l;
+    split_pair(b[0], b[1], &h, &l); oh[2] = h; ol[2] = l;
+    split_pair(b[2], b[3], &h, &l); oh[3] = h; ol[3] = l;
+    *reinterpret_cast<u32x4 *>(y + i * 8) = oh;
+    *reinterpret_cast<u32x4 *>(y + i * 8 + 4) = ol;
+  }
+}
+__global__ void __launch_bounds__(256) split_to_f32_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                           int64_t n_groups) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_groups; i += stride) {
+    const u32x4 h = *reinterpret_cast<const u32x4 *>(x + i * 8), l = *reinterpret_cast<const u32x4 *>(x + i * 8 + 4);
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = split_elem(h, e) + split_elem(l, e);
+      b[e] = split_elem(h, e + 4) + split_elem(l, e + 4);
+    }
+    *reinterpret_cast<f32x4 *>(y + i * 8) = a;
+    *reinterpret_cast<f32x4 *>(y + i * 8 + 4) = b;
+  }
+}
+static unsigned grid_for(int64_t total, int cap) {
+  const int64_t blocks = (total + 255) / 256;
+  return (unsigned)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap);
+}
+hipError_t launch_f32_to_split(const float *x, float *y, int64_t n_groups, hipStream_t s) {
+  hipLaunchKernelGGL(f32_to_split_kernel, dim3(grid_for(n_groups, 8192)), dim3(256), 0, s, x, y, n_groups);
+  return hipGetLastError();
+}
+hipError_t launch_split_to_f32(const float *x, float *y, int64_t n_groups, hipStream_t s) {
+  hipLaunchKernelGGL(split_to_f32_kernel, dim3(grid_for(n_groups, 8192)), dim3(256), 0, s, x, y, n_groups);
   return hipGetLastError();
 }
 
@@ -493,11 +689,19 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreprocParams p) 
       v[c] = (t * p.pre_scale - mean[c]) / stdv[c];
     }
     v[3] = 0.f;
-    if (p.out_nchw) {
+    if (p.out_mode == 1) {
       float *o = p.dst + f * 3 * (int64_t)p.crop * p.crop + (int64_t)cy * p.crop + cx;
       o[0] = v[0];
       o[(int64_t)p.crop * p.crop] = v[1];
       o[2 * (int64_t)p.crop * p.crop] = v[2];
+    } else if (p.out_mode == 2) {
+      u32x4 oh = {0u, 0u, 0u, 0u}, ol = {0u, 0u, 0u, 0u};
+      unsigned h0, l0, h1, l1;
+      split_pair(v[0], v[1], &h0, &l0);
+      split_pair(v[2], 0.f, &h1, &l1);
+      oh[0] = h0; oh[1] = h1; ol[0] = l0; ol[1] = l1;
+      *reinterpret_cast<u32x4 *>(p.dst + i * 8) = oh;
+      *reinterpret_cast<u32x4 *>(p.dst + i * 8 + 4) = ol;
     } else {
       *reinterpret_cast<f32x4 *>(p.dst + i * 4) = f32x4{v[0], v[1], v[2], v[3]};
     }
@@ -521,19 +725,24 @@ hipError_t launch_preprocess(const PreprocParams &p, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // maxpool 3x3 stride 2 pad 1, NHWC; one thread per (output pixel, 4 channels).
 // ---------------------------------------------------------------------------------------------
+template <bool X3>
 __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float *__restrict__ x,
                                                            float *__restrict__ y, int n, int hi, int wi,
-                                                           int ho, int wo, int c4) {
-  const int64_t total = (int64_t)n * ho * wo * c4;
+                                                           int ho, int wo, int cg) {
+  // cg = channel groups per pixel: 4 floats (fp32) or one 32-byte split group of 8 channels
+  constexpr int GF = X3 ? 8 : 4;  // floats-worth of storage per group
+  const int64_t total = (int64_t)n * ho * wo * cg;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int cq = (int)(i % c4);
-    int64_t pix = i / c4;
+    const int g = (int)(i % cg);
+    int64_t pix = i / cg;
     const int ox = (int)(pix % wo);
     pix /= wo;
     const int oy = (int)(pix % ho);
     const int64_t f = pix / ho;
-    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = oy * 2 - 1 + ky;
@@ -542,24 +751,45 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float *__restri
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = ox * 2 - 1 + kx;
         if ((unsigned)ix >= (unsigned)wi) continue;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((f * hi + iy) * wi + ix) * c4 + cq) * 4);
-        m[0] = fmaxf(m[0], v[0]);
-        m[1] = fmaxf(m[1], v[1]);
-        m[2] = fmaxf(m[2], v[2]);
-        m[3] = fmaxf(m[3], v[3]);
+        const float *src = x + (((f * hi + iy) * wi + ix) * cg + g) * GF;
+        if (X3) {
+          const u32x4 h = *reinterpret_cast<const u32x4 *>(src), l = *reinterpret_cast<const u32x4 *>(src + 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], split_elem(h, e) + split_elem(l, e));
+        } else {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(src);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+        }
       }
     }
-    *reinterpret_cast<f32x4 *>(y + i * 4) = m;
+    if (X3) {
+      u32x4 oh, ol;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        unsigned hw, lw;
+        split_pair(m[2 * w], m[2 * w + 1], &hw, &lw);
+        oh[w] = hw;
+        ol[w] = lw;
+      }
+      *reinterpret_cast<u32x4 *>(y + i * 8) = oh;
+      *reinterpret_cast<u32x4 *>(y + i * 8 + 4) = ol;
+    } else {
+      *reinterpret_cast<f32x4 *>(y + i * 4) = f32x4{m[0], m[1], m[2], m[3]};
+    }
   }
 }
 
-hipError_t launch_maxpool3x3s2(const float *x, float *y, int n, int hi, int wi, int c, hipStream_t s) {
-  if (c % 4 != 0) return hipErrorInvalidValue;
+hipError_t launch_maxpool3x3s2(const float *x, float *y, int n, int hi, int wi, int c, int prec, hipStream_t s) {
+  const bool x3 = prec == kPrecBf16x3;
+  if (c % (x3 ? 8 : 4) != 0) return hipErrorInvalidValue;
   const int ho = (hi + 2 - 3) / 2 + 1, wo = (wi + 2 - 3) / 2 + 1;
-  const int64_t total = (int64_t)n * ho * wo * (c / 4);
-  const int64_t blocks = (total + 255) / 256;
-  const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, s, x, y, n, hi, wi, ho, wo, c / 4);
+  const int cg = c / (x3 ? 8 : 4);
+  const int64_t total = (int64_t)n * ho * wo * cg;
+  if (x3)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<true>, dim3(grid_for(total, 8192)), dim3(256), 0, s, x, y, n, hi, wi, ho, wo, cg);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<false>, dim3(grid_for(total, 8192)), dim3(256), 0, s, x, y, n, hi, wi, ho, wo, cg);
   return hipGetLastError();
 }
 
@@ -602,13 +832,26 @@ hipError_t launch_temporal_shift(const float *x, float *y, int64_t n_frames, int
 //   head_pool: grid (n_clips, c/256): thread = one channel, rows streamed coalesced.
 //   head_fc  : grid n_clips: one wave per class round-robin, shuffle reduction.
 // ---------------------------------------------------------------------------------------------
+template <bool X3>
 __global__ void __launch_bounds__(256) head_pool_kernel(const float *__restrict__ feat,
                                                         float *__restrict__ pooled, int rows, int c) {
   const int b = blockIdx.x;
   const int ch = blockIdx.y * 256 + threadIdx.x;
   if (ch >= c) return;
+  float s0 = 0.f, s1 = 0.f;
+  if (X3) {  // element (row, ch): 16-bit halves at group (ch/8): hi at +e, lo at +8+e
+    const unsigned short *src = reinterpret_cast<const unsigned short *>(feat + (size_t)b * rows * c) +
+                                (size_t)(ch >> 3) * 16 + (ch & 7);
+    for (int r = 0; r < rows; ++r) {
+      const unsigned short h = src[(size_t)r * c * 2], l = src[(size_t)r * c * 2 + 8];
+      s0 += __builtin_bit_cast(float, (unsigned)h << 16);
+      s1 += __builtin_bit_cast(float, (unsigned)l << 16);
+    }
+    pooled[(size_t)b * c + ch] = (s0 + s1) / (float)rows;
+    return;
+  }
   const float *src = feat + (size_t)b * rows * c + ch;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s2 = 0.f, s3 = 0.f;
   int r = 0;
   for (; r + 4 <= rows; r += 4) {
     s0 += src[(size_t)(r + 0) * c];
@@ -638,11 +881,15 @@ __global__ void __launch_bounds__(256) head_fc_kernel(const float *__restrict__ 
 }
 
 hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, float *pooled,
-                       float *logits, int n_clips, int n_segment, int hw, int c, int num_class,
+                       float *logits, int n_clips, int n_segment, int hw, int c, int num_class, int prec,
                        hipStream_t s) {
   if (n_clips <= 0 || c <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(head_pool_kernel, dim3(n_clips, (c + 255) / 256), dim3(256), 0, s, feat, pooled,
-                     n_segment * hw, c);
+  if (prec == kPrecBf16x3)
+    hipLaunchKernelGGL(head_pool_kernel<true>, dim3(n_clips, (c + 255) / 256), dim3(256), 0, s, feat, pooled,
+                       n_segment * hw, c);
+  else
+    hipLaunchKernelGGL(head_pool_kernel<false>, dim3(n_clips, (c + 255) / 256), dim3(256), 0, s, feat, pooled,
+                       n_segment * hw, c);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(head_fc_kernel, dim3(n_clips), dim3(256), 0, s, pooled, fc_w, fc_b, logits, c,

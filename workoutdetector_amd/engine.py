@@ -43,14 +43,19 @@ class TsmEngine:
 
     def __init__(self, num_class: int = 12, num_segments: int = 8, height: int = 224, width: int = 224,
                  shift_div: int = 8, is_shift: bool = True, max_clips: int = 32, device: int = 0,
-                 state_dict: Optional[Mapping[str, object]] = None):
+                 state_dict: Optional[Mapping[str, object]] = None, dtype: str = 'f32'):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self.num_class, self.num_segments = int(num_class), int(num_segments)
         self.height, self.width = int(height), int(width)
         self.max_clips, self.device = int(max_clips), int(device)
+        if dtype not in _lib.DTYPES:
+            raise ValueError(f'dtype must be one of {sorted(_lib.DTYPES)}, got {dtype!r}')
+        self.dtype = dtype
+        # layout tsm_preprocess must write for this engine to consume frames in place
+        self.packed_layout = _lib.LAYOUT_NTHWC8S if dtype == 'bf16x3' else _lib.LAYOUT_NTHWC4
         cfg = _lib.TsmConfig(C.sizeof(_lib.TsmConfig), num_class, num_segments, height, width, shift_div,
-                             1 if is_shift else 0, max_clips, device, _lib.DTYPE_F32)
+                             1 if is_shift else 0, max_clips, device, _lib.DTYPES[dtype])
         _lib.check(self._lib.tsm_create(C.byref(cfg), C.byref(self._h)))
         self._finalized = False
         if state_dict is not None:
@@ -159,7 +164,7 @@ class TsmEngine:
         self._need_finalized()
         clips = _as_f32(clips)
         n = clips.shape[0] * self.num_segments
-        cap = n * max(((self.height + 1) // 2) * ((self.width + 1) // 2) * 64, self.height * self.width * 4)
+        cap = n * max(((self.height + 1) // 2) * ((self.width + 1) // 2) * 64, self.height * self.width * 8)
         buf = np.empty(cap, dtype=np.float32)
         shape = (C.c_int64 * 4)()
         _lib.check(self._lib.tsm_forward_tap(self._h, clips.ctypes.data, _lib.MEM_HOST, _lib.LAYOUT_NTCHW,
@@ -224,7 +229,7 @@ def create_model(num_class: int = 2, num_segments: int = 8, base_model: str = 'r
                  checkpoint: Optional[str] = None, device: Optional[object] = None, fc_lr5: bool = True,
                  is_shift: bool = True, shift_div: int = 8, shift_place: str = 'blockres',
                  consensus_type: str = 'avg', img_feature_dim: int = 256, non_local: bool = False,
-                 height: int = 224, width: int = 224, max_clips: int = 32, seed: int = 0,
+                 height: int = 224, width: int = 224, max_clips: int = 32, seed: int = 0, dtype: str = 'f32',
                  **kwargs) -> TsmEngine:
     """Counterpart of the reference factory (tsm.py:422-476) returning a ready TsmEngine.
 
@@ -252,7 +257,8 @@ def create_model(num_class: int = 2, num_segments: int = 8, base_model: str = 'r
     else:
         sd = make_state_dict(seed=seed, num_class=num_class)
     return TsmEngine(num_class=num_class, num_segments=num_segments, height=height, width=width,
-                     shift_div=shift_div, is_shift=is_shift, max_clips=max_clips, device=dev, state_dict=sd)
+                     shift_div=shift_div, is_shift=is_shift, max_clips=max_clips, device=dev, state_dict=sd,
+                     dtype=dtype)
 
 
 # ---- per-op wrappers over the C ABI (device tensors), used by tests ----------------------------------
@@ -277,7 +283,7 @@ def temporal_shift_nhwc(x, n_segment: int, fold_div: int = 8):
 
 
 def conv_bn_act_nhwc(x, w, gamma, beta, mean, var, stride: int = 1, relu: bool = True, residual=None,
-                     shift_segments: int = 0, fold_div: int = 8):
+                     shift_segments: int = 0, fold_div: int = 8, dtype: str = 'f32'):
     """x NHWC [n,h,w,cin], w OIHW; returns NHWC [n,ho,wo,cout]."""
     import torch
     x = x.contiguous()
@@ -290,14 +296,16 @@ def conv_bn_act_nhwc(x, w, gamma, beta, mean, var, stride: int = 1, relu: bool =
     args = [t.contiguous() for t in (w, gamma, beta, mean, var)]
     _lib.check(_lib.load().tsm_conv_bn_act(x.data_ptr(), *[a.data_ptr() for a in args], _ptr(res), y.data_ptr(),
                                            n, hi, wi, cin, cout, k, stride, int(relu), shift_segments, fold_div,
-                                           _stream(x)))
+                                           _lib.DTYPES[dtype], _stream(x)))
     return y
 
 
-def preprocess_frames(frames, resize: int = 256, crop: int = 224, scale_255: bool = False, packed: bool = True):
+def preprocess_frames(frames, resize: int = 256, crop: int = 224, scale_255: bool = False, packed: bool = True,
+                      layout: Optional[int] = None):
     """HIP test transform.  frames: CUDA uint8 or float32 [n,H,W,3] (decoder layout, values 0..255).
-    Returns float32 [n,crop,crop,4] (``packed``: feed ``forward_device(..., layout=LAYOUT_NTHWC4)``) or
-    [n,3,crop,crop]."""
+    Returns float32 [n,crop,crop,4] (``packed``: feed ``forward_device(..., layout=LAYOUT_NTHWC4)``),
+    [n,3,crop,crop] (``packed=False``), or with ``layout=engine.packed_layout`` the packed format of that
+    engine (LAYOUT_NTHWC8S for a bf16x3 engine: a float32-typed buffer [n,crop,crop,8] holding split-bf16)."""
     import torch
     frames = frames.contiguous()
     if frames.dtype == torch.uint8:
@@ -309,10 +317,12 @@ def preprocess_frames(frames, resize: int = 256, crop: int = 224, scale_255: boo
     n, h, w, c = frames.shape
     if c != 3 or not frames.is_cuda:
         raise ValueError('frames must be a CUDA tensor [n,H,W,3]')
-    shape = (n, crop, crop, 4) if packed else (n, 3, crop, crop)
+    if layout is None:
+        layout = _lib.LAYOUT_NTHWC4 if packed else _lib.LAYOUT_NTCHW
+    shape = {_lib.LAYOUT_NTHWC4: (n, crop, crop, 4), _lib.LAYOUT_NTHWC8S: (n, crop, crop, 8),
+             _lib.LAYOUT_NTCHW: (n, 3, crop, crop)}[layout]
     out = torch.empty(shape, dtype=torch.float32, device=frames.device)
-    _lib.check(_lib.load().tsm_preprocess(frames.data_ptr(), pixel, n, h, w, out.data_ptr(),
-                                          _lib.LAYOUT_NTHWC4 if packed else _lib.LAYOUT_NTCHW, resize, crop,
+    _lib.check(_lib.load().tsm_preprocess(frames.data_ptr(), pixel, n, h, w, out.data_ptr(), layout, resize, crop,
                                           int(scale_255), _stream(frames)))
     return out
 

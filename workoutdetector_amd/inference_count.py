@@ -122,14 +122,15 @@ def video_clip_logits(model, video_thwc_u8: torch.Tensor, transform: TestTransfo
     f_lo = starts[lo] // CLIP_STRIDE
     f_hi = min((starts[hi - 1] + CLIP_SPAN) // CLIP_STRIDE, (total + 1) // CLIP_STRIDE)
     even = video_thwc_u8[0::CLIP_STRIDE][f_lo:f_hi]
-    hip_transform = dev is not None and isinstance(transform, TestTransform)
+    hip_transform = dev is not None and isinstance(transform, TestTransform) and hasattr(model, 'packed_layout')
     if hip_transform:
         # HIP path: uint8 frames (+ one zero frame for the padded tail) -> fused resize/crop/normalise
         # kernel -> NHWC4, which the engine consumes in place.
         from .engine import preprocess_frames
-        from ._lib import LAYOUT_NTHWC4
+        packed_layout = model.packed_layout
         even = torch.cat([even, torch.zeros((1,) + tuple(even.shape[1:]), dtype=even.dtype)]).to(dev, non_blocking=True)
-        frames = preprocess_frames(even, resize=transform.size, crop=transform.crop, scale_255=transform.scale_255)
+        frames = preprocess_frames(even, resize=transform.size, crop=transform.crop, scale_255=transform.scale_255,
+                                   layout=packed_layout)
     else:
         if dev is not None:
             even = even.to(dev, non_blocking=True)
@@ -144,7 +145,7 @@ def video_clip_logits(model, video_thwc_u8: torch.Tensor, transform: TestTransfo
     for b in range(0, idx.shape[0], batch_clips):
         clips = frames[idx[b:b + batch_clips]]                                # [b, 8, 3, 224, 224] / [b, 8, 224, 224, 4]
         if hip_transform:
-            out.append(model.forward_device(clips.contiguous(), layout=LAYOUT_NTHWC4).cpu())
+            out.append(model.forward_device(clips.contiguous(), layout=packed_layout).cpu())
         elif dev is not None:
             out.append(model.forward_device(clips.contiguous()).cpu())
         else:
