@@ -13,7 +13,8 @@ sys.path.insert(0, %r)
 from workoutdetector_amd.engine import TsmEngine
 from workoutdetector_amd.weights import make_state_dict
 B = 32
-eng = TsmEngine(max_clips=B, state_dict=make_state_dict(0, 12))
+import os
+eng = TsmEngine(max_clips=B, state_dict=make_state_dict(0, 12), dtype=os.environ.get('TSM_SWEEP_DTYPE', 'f32'))
 x = torch.randn(B, 8, 3, 224, 224, device='cuda')
 for _ in range(3): eng.forward_device(x)
 torch.cuda.synchronize()
@@ -29,6 +30,9 @@ print(json.dumps({k: sorted(v)[len(v)//2] for k, v in acc.items()}))
 res = {}
 for tile in ['default', '128x128', '128x64', '64x64']:
     env = dict(os.environ)
+    env['TSM_AUTOTUNE'] = '1' if tile == 'default' else '0'
+    if len(sys.argv) > 1:
+        env['TSM_SWEEP_DTYPE'] = sys.argv[1]
     if tile != 'default':
         env['TSM_CONV_TILE'] = tile
     out = subprocess.run([sys.executable, '-c', CHILD], env=env, capture_output=True, text=True)

@@ -543,7 +543,7 @@ int tsm_finalize(tsm_engine *e) {
   if (rc) return rc;
   rc = dev_alloc(e, &e->d_in4, frames * 8 * cfg.height * cfg.width);
   if (rc) return rc;
-  rc = dev_alloc(e, &e->d_pooled, (size_t)cfg.max_clips * 2048);
+  rc = dev_alloc(e, &e->d_pooled, frames * 2048);
   if (rc) return rc;
   rc = dev_alloc(e, &e->d_logits, (size_t)cfg.max_clips * cfg.num_class);
   if (rc) return rc;
@@ -820,7 +820,7 @@ int tsm_head(const float *feat, const float *fc_w, const float *fc_b, float *log
     return TSM_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   float *pooled = nullptr;
-  hipError_t st = hipMalloc(reinterpret_cast<void **>(&pooled), (size_t)n_clips * c * sizeof(float));
+  hipError_t st = hipMalloc(reinterpret_cast<void **>(&pooled), (size_t)n_clips * n_segment * c * sizeof(float));
   if (st != hipSuccess) return fail(nullptr, TSM_ERR_HIP, std::string("head scratch: ") + hipGetErrorString(st));
   st = tsm::launch_head(feat, fc_w, fc_b, pooled, logits, n_clips, n_segment, hw, c, num_class, tsm::kPrecF32, s);
   hipError_t st2 = hipStreamSynchronize(s);

@@ -60,7 +60,7 @@ hipError_t launch_maxpool3x3s2(const float *x, float *y, int n, int hi, int wi, 
                                hipStream_t s);
 hipError_t launch_temporal_shift(const float *x, float *y, int64_t n_frames, int n_segment,
                                  int64_t hw, int c, int fold, hipStream_t s);
-// pooled: scratch [n_clips, c]
+// pooled: scratch [n_clips * n_segment, c]
 hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, float *pooled,
                        float *logits, int n_clips, int n_segment, int hw, int c, int num_class, int prec,
                        hipStream_t s);

@@ -827,31 +827,36 @@ hipError_t launch_temporal_shift(const float *x, float *y, int64_t n_frames, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// Head.  logits[b] = fc( mean_{t,hw} feat[b,t,hw,:] ) + bias  (avg-pool, FC and the segment mean
+// Head.  logits[b] = fc( mean_t mean_hw feat[b,t,hw,:] ) + bias  (avg-pool, FC and the segment mean
 // are all linear, so pooling first is exact up to fp32 summation order).  tsm.py:411-419.
-//   head_pool: grid (n_clips, c/256): thread = one channel, rows streamed coalesced.
-//   head_fc  : grid n_clips: one wave per class round-robin, shuffle reduction.
+//   head_pool: grid (n_frames, ...): per-frame average pool into pooled[n_frames, c].
+//   head_fc  : grid n_clips: mean over the clip's frames, one wave per class round-robin.
 // ---------------------------------------------------------------------------------------------
+// head_pool: fp32 -> thread = one channel (rows streamed coalesced); split -> thread = one 32-byte group of
+// 8 channels (two 16-byte loads per row).  grid (n_clips, ceil(threads / 256)).
 template <bool X3>
 __global__ void __launch_bounds__(256) head_pool_kernel(const float *__restrict__ feat,
                                                         float *__restrict__ pooled, int rows, int c) {
   const int b = blockIdx.x;
-  const int ch = blockIdx.y * 256 + threadIdx.x;
-  if (ch >= c) return;
-  float s0 = 0.f, s1 = 0.f;
-  if (X3) {  // element (row, ch): 16-bit halves at group (ch/8): hi at +e, lo at +8+e
-    const unsigned short *src = reinterpret_cast<const unsigned short *>(feat + (size_t)b * rows * c) +
-                                (size_t)(ch >> 3) * 16 + (ch & 7);
+  const int t = blockIdx.y * 256 + threadIdx.x;
+  if (X3) {
+    if (t >= c / 8) return;
+    const float *src = feat + (size_t)b * rows * c + (size_t)t * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int r = 0; r < rows; ++r) {
-      const unsigned short h = src[(size_t)r * c * 2], l = src[(size_t)r * c * 2 + 8];
-      s0 += __builtin_bit_cast(float, (unsigned)h << 16);
-      s1 += __builtin_bit_cast(float, (unsigned)l << 16);
+      const u32x4 h = *reinterpret_cast<const u32x4 *>(src + (size_t)r * c);
+      const u32x4 l = *reinterpret_cast<const u32x4 *>(src + (size_t)r * c + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += split_elem(h, e) + split_elem(l, e);
     }
-    pooled[(size_t)b * c + ch] = (s0 + s1) / (float)rows;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pooled[(size_t)b * c + t * 8 + e] = acc[e] / (float)rows;
     return;
   }
+  const int ch = t;
+  if (ch >= c) return;
   const float *src = feat + (size_t)b * rows * c + ch;
-  float s2 = 0.f, s3 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int r = 0;
   for (; r + 4 <= rows; r += 4) {
     s0 += src[(size_t)(r + 0) * c];
@@ -866,14 +871,19 @@ __global__ void __launch_bounds__(256) head_pool_kernel(const float *__restrict_
 __global__ void __launch_bounds__(256) head_fc_kernel(const float *__restrict__ pooled,
                                                       const float *__restrict__ fc_w,
                                                       const float *__restrict__ fc_b,
-                                                      float *__restrict__ logits, int c, int num_class) {
+                                                      float *__restrict__ logits, int c, int num_class,
+                                                      int n_segment) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float *pv = pooled + (size_t)b * c;
+  const float *pv = pooled + (size_t)b * n_segment * c;  // per-frame pooled features of this clip
   for (int cls = wave; cls < num_class; cls += 4) {
     const float *wv = fc_w + (size_t)cls * c;
     float s = 0.f;
-    for (int k = lane; k < c; k += 64) s += pv[k] * wv[k];
+    for (int k = lane; k < c; k += 64) {
+      float f = 0.f;
+      for (int t = 0; t < n_segment; ++t) f += pv[(size_t)t * c + k];
+      s += (f / (float)n_segment) * wv[k];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) logits[(size_t)b * num_class + cls] = s + fc_b[cls];
@@ -884,16 +894,18 @@ hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, 
                        float *logits, int n_clips, int n_segment, int hw, int c, int num_class, int prec,
                        hipStream_t s) {
   if (n_clips <= 0 || c <= 0) return hipErrorInvalidValue;
+  // stage 1: one workgroup row per FRAME (n_clips * n_segment of them) so the whole chip streams the
+  // feature map; stage 2 averages the frames of a clip and applies the classifier.
   if (prec == kPrecBf16x3)
-    hipLaunchKernelGGL(head_pool_kernel<true>, dim3(n_clips, (c + 255) / 256), dim3(256), 0, s, feat, pooled,
-                       n_segment * hw, c);
+    hipLaunchKernelGGL(head_pool_kernel<true>, dim3(n_clips * n_segment, (c / 8 + 255) / 256), dim3(256), 0, s, feat,
+                       pooled, hw, c);
   else
-    hipLaunchKernelGGL(head_pool_kernel<false>, dim3(n_clips, (c + 255) / 256), dim3(256), 0, s, feat, pooled,
-                       n_segment * hw, c);
+    hipLaunchKernelGGL(head_pool_kernel<false>, dim3(n_clips * n_segment, (c + 255) / 256), dim3(256), 0, s, feat,
+                       pooled, hw, c);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(head_fc_kernel, dim3(n_clips), dim3(256), 0, s, pooled, fc_w, fc_b, logits, c,
-                     num_class);
+                     num_class, n_segment);
   return hipGetLastError();
 }
 
