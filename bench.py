@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 
 GFLOP_PER_CLIP_T8_224 = 65.395          # 2 * (4.0871 GMAC/frame + 24576) * 8, SURVEY.md section 8(d)
 PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA", dense
 
 
 def flops_per_clip(t, h, w, num_class=12):
@@ -105,6 +106,7 @@ def main():
     ap.add_argument('--segments', type=int, default=8)
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alt', action='store_true', help='skip the second run in the other precision mode')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16x3'],
                     help='f32: exact-fp32 MFMA; bf16x3: split-bf16 storage, 3 bf16 MFMAs per product')
     args = ap.parse_args()
@@ -137,56 +139,66 @@ def main():
 
     T, H, W, B = args.segments, args.size, args.size, args.batch
     sd = make_state_dict(0, 12)
-    eng = TsmEngine(num_class=12, num_segments=T, height=H, width=W, max_clips=B, device=local_rank, state_dict=sd,
-                    dtype=args.dtype)
     gen = torch.Generator(device='cuda').manual_seed(rank)
     clips = torch.randn(B, T, 3, H, W, device='cuda', generator=gen)
-    logits = torch.empty(B, 12, device='cuda')
 
-    def step():
-        eng.forward_device(clips, out=logits)
-        return all_gather_logits(logits) if world > 1 else logits
+    def run_mode(dtype, want_launch_times):
+        """W warm-up + K timed steps of one engine; returns wall seconds (max over ranks) and event timings."""
+        eng = TsmEngine(num_class=12, num_segments=T, height=H, width=W, max_clips=B, device=local_rank,
+                        state_dict=sd, dtype=dtype)
+        logits = torch.empty(B, 12, device='cuda')
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    n_timed = min(args.steps, 64)
-    eng.set_layer_timing(n_timed, only_conv3x3=True)   # HIP-event pairs around the dominant kernel's launches
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    assert bool(torch.isfinite(out).all())
+        def step():
+            eng.forward_device(clips, out=logits)
+            return all_gather_logits(logits) if world > 1 else logits
 
-    # Per-launch durations of the timed forwards (events were recorded inside the timed region; reading
-    # them here keeps the host syncs out of it).
-    per_launch = [eng.layer_times_ms(i) for i in range(n_timed)]
-    eng.set_layer_timing(0)
-    # Whole-forward kernel time (one HIP-event pair around all launches of a forward), outside the
-    # wall-clock region because reading it synchronises.
-    fwd_ev_ms = []
-    for _ in range(min(args.steps, 10)):
-        eng.forward_device(clips, out=logits)
-        fwd_ev_ms.append(eng.last_forward_ms)
-    torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        n_timed = min(args.steps, 64)
+        if want_launch_times:
+            eng.set_layer_timing(n_timed, only_conv3x3=True)   # HIP-event pairs around the dominant kernel's launches
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        assert bool(torch.isfinite(out).all())
+        # Per-launch durations of the timed forwards (events were recorded inside the timed region; reading
+        # them here keeps the host syncs out of it).
+        per_launch = [eng.layer_times_ms(i) for i in range(n_timed)] if want_launch_times else []
+        eng.set_layer_timing(0)
+        # Whole-forward kernel time (one HIP-event pair around all launches of a forward), outside the
+        # wall-clock region because reading it synchronises.
+        fwd_ev_ms = []
+        for _ in range(min(args.steps, 10)):
+            eng.forward_device(clips, out=logits)
+            fwd_ev_ms.append(eng.last_forward_ms)
+        torch.cuda.synchronize()
+        t_max = torch.tensor([elapsed], device='cuda')
+        if world > 1:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        tiles = eng.conv_tiles(B)
+        eng.close()
+        return float(t_max.item()), per_launch, sorted(fwd_ev_ms)[len(fwd_ev_ms) // 2], tiles
 
-    t_max = torch.tensor([elapsed], device='cuda')
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
+    elapsed, per_launch, fwd_ms, tiles = run_mode(args.dtype, True)
+    alt = None
+    if not args.no_alt:
+        alt_dtype = 'bf16x3' if args.dtype == 'f32' else 'f32'
+        alt_elapsed, _, alt_fwd_ms, _ = run_mode(alt_dtype, False)
+        alt = (alt_dtype, alt_elapsed, alt_fwd_ms)
 
     if rank == 0:
         clips_total = B * world * args.steps
         value = clips_total / elapsed
         gflop = flops_per_clip(T, H, W) / 1e9
-        fwd_ms = sorted(fwd_ev_ms)[len(fwd_ev_ms) // 2]
         fwd_achieved = gflop * B / fwd_ms  # GFLOP / ms == TFLOP/s
         from oracle.tsm_oracle import layer_table
         frames = B * T
@@ -196,41 +208,54 @@ def main():
         dom_gflop = dom_gflop.pop()
         # The engine tunes the tile shape per layer, so the 3x3 convs may run on more than one
         # instantiation of conv_igemm_f32: the dominant kernel is the instantiation with the most time.
-        tiles = eng.conv_tiles(B)
         groups = {}
         for r in dom:
             groups.setdefault(tiles[r['name']], []).extend(d[r['name']] for d in per_launch)
         dom_tile, dom_ms = max(groups.items(), key=lambda kv: sum(kv[1]))
-        dom_kernel = 'conv_igemm_f32<%s, 2, 2, 3, false, false>' % dom_tile.replace('x', ', ')
+        prec_id = 1 if args.dtype == 'bf16x3' else 0
+        dom_kernel = 'conv_igemm<%s, 2, 2, 3, false, false, %d>' % (dom_tile.replace('x', ', '), prec_id)
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
+        peak_name = ('dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); the kernel executes 3 MFMA FLOPs per algorithmic FLOP'
+                     if args.dtype == 'bf16x3' else 'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), dense')
         dom_avg_ms = sum(dom_ms) / len(dom_ms)
         achieved = dom_gflop / dom_avg_ms
         line = {
             'metric': 'clips/sec (8x3x224x224 TSM-R50)', 'value': round(value, 2), 'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'TSM-R50 {T}-seg {H}x{W} 12-class inference, batch {B} clips per GPU, '
-                                   'fp32 NHWC, device-resident input (BASELINE.json configs[1])',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f'TSM-R50 {T}-seg {H}x{W} 12-class inference, batch {B} clips per GPU, ' +
+                                   '%s NHWC, device-resident input (BASELINE.json configs[1])' % args.dtype,
                        'clips_per_gpu': B, 'num_segments': T, 'height': H, 'width': W, 'num_class': 12,
                        'weights': 'seeded random init (no trained weights offline)',
                        'parallelism': f'clip-sharded x{world}, RCCL all-gather of logits' if world > 1 else 'single GPU'},
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'traffic': measured_traffic(B, T, H, W, dom_kernel),
                          'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/traffic.json)',
                          'kernel': dom_kernel + ' (3x3 convs of layer2-4, %d of 13 launches per forward)'
                                    % (len(dom_ms) // len(per_launch)),
                          'gflop_per_launch': round(dom_gflop, 3), 'avg_launch_ms': round(dom_avg_ms, 4),
                          'launches_timed': len(dom_ms),
-                         'peak_name': 'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), dense',
+                         'peak_name': peak_name,
                          'forward_achieved': round(fwd_achieved, 2),
-                         'forward_frac': round(fwd_achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         'forward_frac': round(fwd_achieved / peak, 4),
                          'forward_gflop': round(gflop * B, 3), 'forward_kernel_ms': round(fwd_ms, 4)},
         }
+        if alt is not None:
+            a_dtype, a_elapsed, a_fwd = alt
+            line['alt_precision'] = {
+                'dtype': a_dtype, 'value': round(clips_total / a_elapsed, 2), 'unit': 'clips/s',
+                'ms_per_step': round(1e3 * a_elapsed / args.steps, 4), 'forward_kernel_ms': round(a_fwd, 4),
+                'forward_algorithmic_tflops': round(gflop * B / a_fwd, 2),
+                'note': ('same engine, same inputs, same steps/warmup, TSM_DTYPE_BF16X3: split-bf16 storage (hi/lo), '
+                         'a*b = ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; passes the '
+                         'same parity tests (logits within 5e-6 of the fp32 oracle, bar 1e-3; tests/test_bf16x3_gpu.py); '
+                         'not the headline because it is not bit-level fp32 arithmetic')
+                        if a_dtype == 'bf16x3' else 'exact-fp32 MFMA mode of the same engine'}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, T, H, W)
         print(json.dumps(line), flush=True)
-    eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
