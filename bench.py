@@ -107,7 +107,7 @@ def main():
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the second run in the other precision mode')
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16x3'],
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16x3', 'bf16'],
                     help='f32: exact-fp32 MFMA; bf16x3: split-bf16 storage, 3 bf16 MFMAs per product')
     args = ap.parse_args()
 
@@ -212,15 +212,16 @@ def main():
         for r in dom:
             groups.setdefault(tiles[r['name']], []).extend(d[r['name']] for d in per_launch)
         dom_tile, dom_ms = max(groups.items(), key=lambda kv: sum(kv[1]))
-        prec_id = 1 if args.dtype == 'bf16x3' else 0
+        prec_id = {'f32': 0, 'bf16x3': 1, 'bf16': 2}[args.dtype]
         dom_kernel = 'conv_igemm<%s, 2, 2, 3, false, false, %d>' % (dom_tile.replace('x', ', '), prec_id)
-        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16x3' else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         peak_name = ('dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); the kernel executes 3 MFMA FLOPs per algorithmic FLOP'
-                     if args.dtype == 'bf16x3' else 'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), dense')
+                     if args.dtype == 'bf16x3' else 'dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)' if args.dtype == 'bf16'
+                     else 'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), dense')
         dom_avg_ms = sum(dom_ms) / len(dom_ms)
         achieved = dom_gflop / dom_avg_ms
         line = {
-            'metric': 'clips/sec (8x3x224x224 TSM-R50)', 'value': round(value, 2), 'unit': 'clips/s',
+            'metric': f'clips/sec ({T}x3x{H}x{W} TSM-R50)', 'value': round(value, 2), 'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',

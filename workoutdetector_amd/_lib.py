@@ -11,10 +11,10 @@ from .build import LIB_PATH
 ABI_VERSION = 2
 
 MEM_HOST, MEM_DEVICE = 0, 1
-LAYOUT_NTCHW, LAYOUT_NTHWC, LAYOUT_NTHWC4, LAYOUT_NTHWC8S = 0, 1, 2, 3
+LAYOUT_NTCHW, LAYOUT_NTHWC, LAYOUT_NTHWC4, LAYOUT_NTHWC8S, LAYOUT_NTHWC8B = 0, 1, 2, 3, 4
 PIXEL_U8, PIXEL_F32 = 0, 1
-DTYPE_F32, DTYPE_BF16X3 = 0, 1
-DTYPES = {'f32': DTYPE_F32, 'bf16x3': DTYPE_BF16X3}
+DTYPE_F32, DTYPE_BF16X3, DTYPE_BF16 = 0, 1, 2
+DTYPES = {'f32': DTYPE_F32, 'bf16x3': DTYPE_BF16X3, 'bf16': DTYPE_BF16}
 
 STATUS_NAMES = {0: 'TSM_OK', -1: 'TSM_ERR_INVALID_ARG', -2: 'TSM_ERR_HIP', -3: 'TSM_ERR_NOT_FINALIZED',
                 -4: 'TSM_ERR_MISSING_TENSOR', -5: 'TSM_ERR_SHAPE', -6: 'TSM_ERR_CAPACITY',

@@ -67,6 +67,13 @@ float bf2f(uint16_t h) {
   std::memcpy(&f, &u, 4);
   return f;
 }
+// fp32 -> bf16, two elements per float slot (the vector shrinks to half its length).
+void to_bf16(std::vector<float> *v) {
+  std::vector<float> out((v->size() + 1) / 2, 0.f);
+  uint16_t *o = reinterpret_cast<uint16_t *>(out.data());
+  for (size_t i = 0; i < v->size(); ++i) o[i] = f2bf((*v)[i]);
+  v->swap(out);
+}
 // In place: every group of 8 consecutive floats becomes [hi x8 | lo x8] bf16 (32 bytes, same size).
 void to_split(std::vector<float> *v) {
   uint16_t g[16];
@@ -151,8 +158,8 @@ void build_topology(tsm_engine *e) {
   stem.wkey = "base_model.conv1.weight";
   stem.bnp = "base_model.bn1";
   stem.cin = 3; stem.cout = 64; stem.k = 7; stem.stride = 2;
-  stem.cp = e->prec == tsm::kPrecBf16x3 ? 8 : 4;  // split format works on 8-channel groups
-  stem.kp = round_up(7 * 7 * stem.cp, 32);
+  stem.cp = e->prec == tsm::kPrecF32 ? 4 : 8;  // the bf16 formats work on 8-channel groups
+  stem.kp = round_up(7 * 7 * stem.cp, e->prec == tsm::kPrecBf16 ? 64 : 32);
   e->convs.push_back(stem);
   int cin = 64;
   for (int li = 0; li < 4; ++li) {
@@ -328,7 +335,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
 
   const int prec = e->prec;
   const float *in4 = e->d_in4;
-  if (layout == TSM_LAYOUT_NTHWC4 || layout == TSM_LAYOUT_NTHWC8S) {
+  if (layout >= TSM_LAYOUT_NTHWC4) {
     in4 = d_clips;  // already packed by tsm_preprocess: consumed in place
   } else {
     TSM_LAUNCH(e, s, tsm::launch_pack_input(d_clips, e->d_in4, n, cfg.height, cfg.width,
@@ -394,11 +401,12 @@ int check_forward_args(tsm_engine *e, const void *clips, int memkind, int layout
   if (!e->finalized) return fail(e, TSM_ERR_NOT_FINALIZED, "tsm_finalize has not been called");
   if (!clips) return fail(e, TSM_ERR_INVALID_ARG, "clips is NULL");
   if (memkind != TSM_MEM_HOST && memkind != TSM_MEM_DEVICE) return fail(e, TSM_ERR_INVALID_ARG, "bad memkind");
-  if (layout < TSM_LAYOUT_NTCHW || layout > TSM_LAYOUT_NTHWC8S) return fail(e, TSM_ERR_INVALID_ARG, "bad layout");
-  if ((layout == TSM_LAYOUT_NTHWC4 || layout == TSM_LAYOUT_NTHWC8S) && memkind != TSM_MEM_DEVICE)
-    return fail(e, TSM_ERR_INVALID_ARG, "packed layouts (NTHWC4 / NTHWC8S) are device-memory layouts");
+  if (layout < TSM_LAYOUT_NTCHW || layout > TSM_LAYOUT_NTHWC8B) return fail(e, TSM_ERR_INVALID_ARG, "bad layout");
+  if (layout >= TSM_LAYOUT_NTHWC4 && memkind != TSM_MEM_DEVICE)
+    return fail(e, TSM_ERR_INVALID_ARG, "packed layouts (NTHWC4 / NTHWC8S / NTHWC8B) are device-memory layouts");
   if ((layout == TSM_LAYOUT_NTHWC4 && e->prec != tsm::kPrecF32) ||
-      (layout == TSM_LAYOUT_NTHWC8S && e->prec != tsm::kPrecBf16x3))
+      (layout == TSM_LAYOUT_NTHWC8S && e->prec != tsm::kPrecBf16x3) ||
+      (layout == TSM_LAYOUT_NTHWC8B && e->prec != tsm::kPrecBf16))
     return fail(e, TSM_ERR_INVALID_ARG, "packed layout does not match the engine dtype");
   if (n_clips <= 0) return fail(e, TSM_ERR_INVALID_ARG, "n_clips must be positive");
   if (n_clips > e->cfg.max_clips)
@@ -426,10 +434,10 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
     return fail(nullptr, TSM_ERR_INVALID_ARG, "height/width must be >= 32");
   if (cfg->shift_div <= 0 || (64 % cfg->shift_div) != 0 || (64 / cfg->shift_div) % 4 != 0)
     return fail(nullptr, TSM_ERR_UNSUPPORTED, "shift_div must divide 64 with fold % 4 == 0 (8 or 16... )");
-  if (cfg->dtype != TSM_DTYPE_F32 && cfg->dtype != TSM_DTYPE_BF16X3)
-    return fail(nullptr, TSM_ERR_UNSUPPORTED, "dtype must be TSM_DTYPE_F32 or TSM_DTYPE_BF16X3");
-  if (cfg->dtype == TSM_DTYPE_BF16X3 && (64 / cfg->shift_div) % 8 != 0)
-    return fail(nullptr, TSM_ERR_UNSUPPORTED, "TSM_DTYPE_BF16X3 needs fold % 8 == 0 (shift_div <= 8)");
+  if (cfg->dtype != TSM_DTYPE_F32 && cfg->dtype != TSM_DTYPE_BF16X3 && cfg->dtype != TSM_DTYPE_BF16)
+    return fail(nullptr, TSM_ERR_UNSUPPORTED, "dtype must be TSM_DTYPE_F32, TSM_DTYPE_BF16X3 or TSM_DTYPE_BF16");
+  if (cfg->dtype != TSM_DTYPE_F32 && (64 / cfg->shift_div) % 8 != 0)
+    return fail(nullptr, TSM_ERR_UNSUPPORTED, "the bf16 formats need fold % 8 == 0 (shift_div <= 8)");
   int ndev = 0;
   hipError_t st = hipGetDeviceCount(&ndev);
   if (st != hipSuccess || ndev <= 0)
@@ -437,7 +445,8 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, TSM_ERR_INVALID_ARG, "bad device_id");
   tsm_engine *e = new tsm_engine();
   e->cfg = *cfg;
-  e->prec = cfg->dtype == TSM_DTYPE_BF16X3 ? tsm::kPrecBf16x3 : tsm::kPrecF32;
+  e->prec = cfg->dtype == TSM_DTYPE_BF16X3 ? tsm::kPrecBf16x3
+            : cfg->dtype == TSM_DTYPE_BF16 ? tsm::kPrecBf16 : tsm::kPrecF32;
   if (const char *at = getenv("TSM_AUTOTUNE")) e->autotune = atoi(at) != 0;
   build_topology(e);
   st = hipSetDevice(cfg->device_id);
@@ -506,6 +515,7 @@ int tsm_finalize(tsm_engine *e) {
     fold_and_pack(w->data.data(), g->data.data(), b->data.data(), m->data.data(), v->data.data(), c.cout,
                   c.cin, c.k, c.cp, c.kp, &wp, &bias);
     if (e->prec == tsm::kPrecBf16x3) to_split(&wp);
+    if (e->prec == tsm::kPrecBf16) to_bf16(&wp);
     int rc = dev_alloc(e, &c.d_w, wp.size());
     if (rc) return rc;
     rc = dev_alloc(e, &c.d_b, bias.size());
@@ -616,7 +626,7 @@ int tsm_forward_tap(tsm_engine *e, const void *clips, int32_t memkind, int32_t l
   const int64_t elems = tap.shape[0] * tap.shape[1] * tap.shape[2] * tap.shape[3];
   for (int i = 0; i < 4; ++i) out_shape[i] = tap.shape[i];
   if (elems > out_capacity) return fail(e, TSM_ERR_CAPACITY, "tap output buffer too small");
-  if (e->prec == tsm::kPrecBf16x3) {  // taps are reported as fp32 whatever the storage format
+  if (e->prec != tsm::kPrecF32) {  // taps are reported as fp32 whatever the storage format
     if (!e->d_tap) {
       const size_t cap = e->buf_elems > (size_t)e->cfg.max_clips * e->cfg.num_segments * 8 * e->cfg.height * e->cfg.width
                              ? e->buf_elems
@@ -624,7 +634,7 @@ int tsm_forward_tap(tsm_engine *e, const void *clips, int32_t memkind, int32_t l
       rc = dev_alloc(e, &e->d_tap, cap);
       if (rc) return rc;
     }
-    TSM_HIP(e, tsm::launch_split_to_f32(tap.ptr, e->d_tap, elems / 8, s));
+    TSM_HIP(e, tsm::launch_to_f32(tap.ptr, e->d_tap, elems / 8, e->prec, s));
     tap.ptr = e->d_tap;
   }
   TSM_HIP(e, hipMemcpyAsync(out, tap.ptr, (size_t)elems * sizeof(float),
@@ -704,21 +714,24 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
                     const float *var, const float *residual, float *y, int32_t n, int32_t hi, int32_t wi,
                     int32_t cin, int32_t cout, int32_t k, int32_t stride, int32_t relu, int32_t shift_segments,
                     int32_t fold_div, int32_t dtype, void *stream) {
-  if (dtype != TSM_DTYPE_F32 && dtype != TSM_DTYPE_BF16X3) return fail(nullptr, TSM_ERR_UNSUPPORTED, "bad dtype");
-  const int prec = dtype == TSM_DTYPE_BF16X3 ? tsm::kPrecBf16x3 : tsm::kPrecF32;
-  const bool x3 = prec == tsm::kPrecBf16x3;
+  if (dtype != TSM_DTYPE_F32 && dtype != TSM_DTYPE_BF16X3 && dtype != TSM_DTYPE_BF16)
+    return fail(nullptr, TSM_ERR_UNSUPPORTED, "bad dtype");
+  const int prec = dtype == TSM_DTYPE_BF16X3 ? tsm::kPrecBf16x3 : dtype == TSM_DTYPE_BF16 ? tsm::kPrecBf16 : tsm::kPrecF32;
+  const bool x3 = prec != tsm::kPrecF32;  // any non-fp32 storage format: convert at the boundary
   if (!x || !w || !gamma || !beta || !mean || !var || !y) return fail(nullptr, TSM_ERR_INVALID_ARG, "NULL pointer");
   if (k != 1 && k != 3 && k != 7) return fail(nullptr, TSM_ERR_UNSUPPORTED, "k must be 1, 3 or 7");
   if (stride != 1 && stride != 2) return fail(nullptr, TSM_ERR_UNSUPPORTED, "stride must be 1 or 2");
   const bool stem = (k == 7);
   if (stem ? (cin != 3) : (cin % 32 != 0 || (cin & (cin - 1)) != 0))
     return fail(nullptr, TSM_ERR_UNSUPPORTED, "cin must be 3 (k=7) or a power of two >= 32");
+  if (prec == tsm::kPrecBf16 && !stem && cin % 64 != 0)
+    return fail(nullptr, TSM_ERR_UNSUPPORTED, "TSM_DTYPE_BF16 needs cin % 64 == 0");
   if (cout % 64 != 0) return fail(nullptr, TSM_ERR_UNSUPPORTED, "cout must be a multiple of 64");
   hipStream_t s = static_cast<hipStream_t>(stream);
   ConvLayer c;
   c.cin = cin; c.cout = cout; c.k = k; c.stride = stride;
   c.cp = stem ? (x3 ? 8 : 4) : cin;
-  c.kp = round_up(k * k * c.cp, 32);
+  c.kp = round_up(k * k * c.cp, prec == tsm::kPrecBf16 ? 64 : 32);
   std::vector<float> hw_((size_t)cout * cin * k * k), hg(cout), hb(cout), hm(cout), hv(cout), wp, bias;
 #define TSM_HIP0(call)                                                                              \
   do {                                                                                              \
@@ -732,7 +745,8 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
   TSM_HIP0(hipMemcpy(hm.data(), mean, cout * sizeof(float), hipMemcpyDeviceToHost));
   TSM_HIP0(hipMemcpy(hv.data(), var, cout * sizeof(float), hipMemcpyDeviceToHost));
   fold_and_pack(hw_.data(), hg.data(), hb.data(), hm.data(), hv.data(), cout, cin, k, c.cp, c.kp, &wp, &bias);
-  if (x3) to_split(&wp);
+  if (prec == tsm::kPrecBf16x3) to_split(&wp);
+  if (prec == tsm::kPrecBf16) to_bf16(&wp);
   float *d_w = nullptr, *d_b = nullptr, *d_x4 = nullptr, *d_xs = nullptr, *d_rs = nullptr, *d_ys = nullptr;
   TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_w), wp.size() * sizeof(float)));
   TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_b), bias.size() * sizeof(float)));
@@ -750,7 +764,7 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
     xin = d_x4;
   } else if (x3) {
     TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_xs), (size_t)n * hi * wi * cin * sizeof(float)));
-    TSM_HIP0(tsm::launch_f32_to_split(x, d_xs, (int64_t)n * hi * wi * cin / 8, s));
+    TSM_HIP0(tsm::launch_from_f32(x, d_xs, (int64_t)n * hi * wi * cin / 8, prec, s));
     xin = d_xs;
   }
   if (x3) {
@@ -758,14 +772,14 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
     yout = d_ys;
     if (residual) {
       TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_rs), out_elems * sizeof(float)));
-      TSM_HIP0(tsm::launch_f32_to_split(residual, d_rs, (int64_t)out_elems / 8, s));
+      TSM_HIP0(tsm::launch_from_f32(residual, d_rs, (int64_t)out_elems / 8, prec, s));
       rin = d_rs;
     }
   }
   tsm::ConvParams p = make_params(c, xin, rin, yout, n, hi, wi, relu != 0, shift_segments,
                                   fold_div > 0 ? fold_div : 1, prec);
   hipError_t st = tsm::launch_conv(p, k, s);
-  if (st == hipSuccess && x3) st = tsm::launch_split_to_f32(d_ys, y, (int64_t)out_elems / 8, s);
+  if (st == hipSuccess && x3) st = tsm::launch_to_f32(d_ys, y, (int64_t)out_elems / 8, prec, s);
   hipError_t st2 = hipStreamSynchronize(s);
   (void)hipFree(d_w);
   (void)hipFree(d_b);
@@ -793,8 +807,9 @@ int tsm_preprocess(const void *frames, int32_t pixel, int32_t n, int32_t h, int3
   if (!frames || !out || n <= 0 || h <= 0 || w <= 0 || resize <= 0 || crop <= 0)
     return fail(nullptr, TSM_ERR_INVALID_ARG, "bad preprocess arguments");
   if (pixel != TSM_PIXEL_U8 && pixel != TSM_PIXEL_F32) return fail(nullptr, TSM_ERR_INVALID_ARG, "bad pixel type");
-  if (out_layout != TSM_LAYOUT_NTHWC4 && out_layout != TSM_LAYOUT_NTCHW && out_layout != TSM_LAYOUT_NTHWC8S)
-    return fail(nullptr, TSM_ERR_INVALID_ARG, "out_layout must be NTHWC4, NTHWC8S or NTCHW");
+  if (out_layout != TSM_LAYOUT_NTHWC4 && out_layout != TSM_LAYOUT_NTCHW && out_layout != TSM_LAYOUT_NTHWC8S &&
+      out_layout != TSM_LAYOUT_NTHWC8B)
+    return fail(nullptr, TSM_ERR_INVALID_ARG, "out_layout must be NTHWC4, NTHWC8S, NTHWC8B or NTCHW");
   tsm::PreprocParams p{};
   p.src = frames; p.dst = out; p.n = n; p.h = h; p.w = w;
   // torchvision 0.13 Resize(int): short side -> resize, long side -> int(resize * long / short)
@@ -806,7 +821,8 @@ int tsm_preprocess(const void *frames, int32_t pixel, int32_t n, int32_t h, int3
   p.left = (int)std::nearbyint((p.nw - crop) / 2.0);
   p.crop = crop;
   p.src_is_u8 = pixel == TSM_PIXEL_U8;
-  p.out_mode = out_layout == TSM_LAYOUT_NTCHW ? 1 : (out_layout == TSM_LAYOUT_NTHWC8S ? 2 : 0);
+  p.out_mode = out_layout == TSM_LAYOUT_NTCHW ? 1 : out_layout == TSM_LAYOUT_NTHWC8S ? 2
+               : out_layout == TSM_LAYOUT_NTHWC8B ? 3 : 0;
   p.pre_scale = scale_255 ? 1.0f / 255.0f : 1.0f;
   hipError_t st = tsm::launch_preprocess(p, static_cast<hipStream_t>(stream));
   if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,

@@ -25,7 +25,7 @@ struct ConvParams {
   int prec;  // kPrecF32 | kPrecBf16x3 (storage format of x, w, res, y and the MFMA used)
 };
 
-enum ConvPrec { kPrecF32 = 0, kPrecBf16x3 = 1 };
+enum ConvPrec { kPrecF32 = 0, kPrecBf16x3 = 1, kPrecBf16 = 2 };
 
 enum ConvTile { kTileAuto = 0, kTile128x128 = 1, kTile128x64 = 2, kTile64x64 = 3, kNumTiles = 4 };
 // Is `tile` usable for this problem (Cout divisibility)?
@@ -36,12 +36,12 @@ hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s);
 // Tile rows the heuristics would pick (exposed for tests / DESIGN notes).
 void conv_tile_shape(const ConvParams &p, int *bm, int *bn);
 
-// prec == kPrecF32: dst is NHWC4 fp32; kPrecBf16x3: dst is NHWC8 split-bf16 (32 bytes per pixel).
+// prec == kPrecF32: dst is NHWC4 fp32; kPrecBf16x3: NHWC8 split-bf16 (32 B/pixel); kPrecBf16: NHWC8 bf16 (16 B).
 hipError_t launch_pack_input(const float *src, float *dst, int64_t n_frames, int h, int w,
                              int nchw, int prec, hipStream_t s);
-// fp32 [n_groups*8] <-> split-bf16 groups of [hi x8 | lo x8] (same byte size)
-hipError_t launch_f32_to_split(const float *x, float *y, int64_t n_groups, hipStream_t s);
-hipError_t launch_split_to_f32(const float *x, float *y, int64_t n_groups, hipStream_t s);
+// fp32 [n8 * 8 channels] <-> the storage format of `prec` (kPrecBf16x3 or kPrecBf16)
+hipError_t launch_from_f32(const float *x, float *y, int64_t n8, int prec, hipStream_t s);
+hipError_t launch_to_f32(const float *x, float *y, int64_t n8, int prec, hipStream_t s);
 // Fused test transform: [n,h,w,3] u8|f32 frames -> resize (short side -> `resize`, bilinear, no
 // antialias, align_corners=False) -> centre crop -> ImageNet normalise -> NHWC4 (out_nchw=0) or NCHW.
 struct PreprocParams {
@@ -51,7 +51,7 @@ struct PreprocParams {
   int nh, nw;         // resized size
   int top, left, crop;
   int src_is_u8;
-  int out_mode;       // 0 = NHWC4 fp32, 1 = NCHW fp32, 2 = NHWC8 split-bf16
+  int out_mode;       // 0 = NHWC4 fp32, 1 = NCHW fp32, 2 = NHWC8 split-bf16, 3 = NHWC8 bf16
   float pre_scale;    // 1/255 when frames are to be scaled to [0,1] first, else 1
 };
 hipError_t launch_preprocess(const PreprocParams &p, hipStream_t s);

@@ -59,6 +59,10 @@ __device__ __forceinline__ float split_elem(u32x4 half8, int e) {
   const unsigned w = half8[e >> 1];
   return __builtin_bit_cast(float, (e & 1) ? (w & 0xFFFF0000u) : (w << 16));
 }
+__device__ __forceinline__ unsigned pack_bf16(float x0, float x1) {  // element 0 in the low half
+  const bf16x2 h = {(__bf16)x0, (__bf16)x1};
+  return __builtin_bit_cast(unsigned, h);
+}
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned *hi, unsigned *lo) {
   const bf16x2 h = {(__bf16)x0, (__bf16)x1};  // v_cvt_pk_bf16_f32, round to nearest even
   const unsigned hw = __builtin_bit_cast(unsigned, h);
@@ -83,6 +87,9 @@ template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PR
 __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   constexpr bool X3 = PREC == kPrecBf16x3;
+  constexpr bool BF = PREC == kPrecBf16;   // plain bf16 storage, one bf16 MFMA per product (config 5)
+  constexpr int EB = BF ? 2 : 4;           // bytes per stored element
+  constexpr int KC = 128 / EB;             // channels per K-step (an LDS row is always 128 bytes)
   static_assert(!SHIFT || KS == 1, "the temporal shift is fused into 1x1 convs only");
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -112,16 +119,17 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   const int n_first = m0 / HoWo;
   const int frame0 = SHIFT ? (n_first > 0 ? n_first - 1 : 0) : n_first;
   const size_t frame_elems = (size_t)p.Hi * p.Wi * p.C;
-  const size_t a_bytes = ((size_t)p.N - frame0) * frame_elems * 4;
+  const size_t a_bytes = ((size_t)p.N - frame0) * frame_elems * EB;
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(p.x + (size_t)frame0 * frame_elems), 0,
+      const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)frame0 * frame_elems * EB), 0,
       (int)(a_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : a_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(p.w + (size_t)n0 * p.Kp), 0, BN * p.Kp * 4, 0x00020000);
+      const_cast<char *>(reinterpret_cast<const char *>(p.w) + (size_t)n0 * p.Kp * EB), 0, BN * p.Kp * EB,
+      0x00020000);
 
   // ---- per-thread loader state: 8 threads per 32-float row, 32 rows per pass -------------------
   const int chunk = tid & 7, lrow = tid >> 3;
-  const int frame_bytes = (int)(frame_elems * 4);
+  const int frame_bytes = (int)(frame_elems * EB);
   unsigned a_off[APASS];                       // byte offset of (row, tap 0, this thread's chunk)
   unsigned a_offp[SHIFT ? APASS : 1], a_offm[SHIFT ? APASS : 1];
   unsigned a_mask[KS == 3 ? APASS : 1];
@@ -140,7 +148,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
       a_iy[pp] = iy0;
       a_ix[pp] = ix0;
     } else {
-      const int base = (n - frame0) * frame_bytes + ((iy0 * p.Wi + ix0) * p.C + chunk * 4) * 4;
+      const int base = (n - frame0) * frame_bytes + (iy0 * p.Wi + ix0) * p.C * EB + chunk * 16;
       a_off[pp] = (KS == 1 && !ok) ? kInvalid : (unsigned)base;
       if (KS == 3) {
         unsigned mask = 0;
@@ -161,7 +169,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   }
   unsigned b_off[BPASS];
 #pragma unroll
-  for (int pp = 0; pp < BPASS; ++pp) b_off[pp] = (unsigned)(((lrow + 32 * pp) * p.Kp + chunk * 4) * 4);
+  for (int pp = 0; pp < BPASS; ++pp) b_off[pp] = (unsigned)((lrow + 32 * pp) * p.Kp * EB + chunk * 16);
 
   f32x4 ra[APASS], rb[BPASS];
 
@@ -186,7 +194,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
       // channels [0,fold) <- frame t+1, [fold,2fold) <- frame t-1, rest <- frame t.  Kept as AND/OR
       // masks: a three-way select over the per-row offset arrays is turned into a scratch-memory
       // table by the compiler, which serialises the loader behind vmcnt(0).
-      const int c = kt * kBK + (X3 ? (chunk >> 1) * 8 : chunk * 4);
+      const int c = kt * KC + (X3 ? (chunk >> 1) * 8 : (BF ? chunk * 8 : chunk * 4));
       k.mp = 0u - (unsigned)(c < p.fold);
       k.mm = (0u - (unsigned)(c < 2 * p.fold)) & ~k.mp;
       k.m0 = ~(k.mp | k.mm);
@@ -194,10 +202,10 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
     k.tap = 0;
     k.tap_off = 0;
     if (KS == 3) {  // C >= 32 so a K-step never straddles a tap: tap and its offset are scalars
-      k.tap = (kt * kBK) >> (p.logC4 + 2);
-      const int c0 = kt * kBK - k.tap * p.C;
+      k.tap = (kt * KC) >> (p.logC4 + 2);
+      const int c0 = kt * KC - k.tap * p.C;
       const int ky = k.tap / 3, kx = k.tap - ky * 3;
-      k.tap_off = ((ky * p.Wi + kx) * p.C + c0) * 4;
+      k.tap_off = ((ky * p.Wi + kx) * p.C + c0) * EB;
     }
     return k;
   };
@@ -325,28 +333,58 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
         }
   };
 
+  // ---- plain bf16: a 128-byte LDS row is 64 channels = four k16-groups; group q, lane half h reads the 8
+  // channels 16q + 8h (one ds_read_b128 per operand tile per MFMA).
+  u32x4 af16[4][TM], bf16f[4][TN];
+  auto frag_load_bf = [&](int buf, int qg) {
+    const float *As = smem + buf * (BM + BN) * kLds + (wm * WTM + l31) * kLds + qg * 8 + half * 4;
+    const float *Bs = smem + buf * (BM + BN) * kLds + BM * kLds + (wn * WTN + l31) * kLds + qg * 8 + half * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af16[qg][i] = *reinterpret_cast<const u32x4 *>(As + i * 32 * kLds);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf16f[qg][j] = *reinterpret_cast<const u32x4 *>(Bs + j * 32 * kLds);
+  };
+  constexpr int NMFMA_BF = TM * TN;
+  auto mfma_bf = [&](int qg, int item0, int nitems, auto &&inject) {
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af16[qg][i]),
+                                                            __builtin_bit_cast(bf16x8, bf16f[qg][j]), acc[i][j], 0, 0, 0);
+        ++cnt;
+        const int done = (cnt * nitems) / NMFMA_BF, before = ((cnt - 1) * nitems) / NMFMA_BF;
+#pragma unroll
+        for (int it = before; it < done; ++it) {
+          inject(item0 + it);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+  };
+
   // Residual tile: fetched before the K loop (it does not depend on it) in the epilogue's own
   // row-major 16-B mapping, so its HBM latency hides under the MFMAs.  Rows past M read as zeros.
-  constexpr int EW = X3 ? 8 : 4;       // channels per thread per pass (split: one 32-byte group)
+  constexpr int EW = (X3 || BF) ? 8 : 4;  // channels per thread per pass (split: one 32-byte group; bf16: 16 bytes)
   constexpr int TPR = BN / EW;         // threads per output row
   constexpr int RPP = 256 / TPR;       // rows per pass
   constexpr int EPASS = BM / RPP;
   const int ecol = (tid % TPR) * EW, erow = tid / TPR;
-  f32x4 rres[(RES && !X3) ? EPASS : 1];
-  u32x4 rres_h[(RES && X3) ? EPASS : 1], rres_l[(RES && X3) ? EPASS : 1];
-  if (RES && X3) {
-    const size_t r_bytes = ((size_t)p.M - m0) * p.Cout * 4;
+  f32x4 rres[(RES && !X3 && !BF) ? EPASS : 1];
+  u32x4 rres_h[(RES && (X3 || BF)) ? EPASS : 1], rres_l[(RES && X3) ? EPASS : 1];
+  if (RES && (X3 || BF)) {
+    const size_t r_bytes = ((size_t)p.M - m0) * p.Cout * EB;
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.res + (size_t)m0 * p.Cout), 0,
+        const_cast<char *>(reinterpret_cast<const char *>(p.res) + (size_t)m0 * p.Cout * EB), 0,
         (int)(r_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : r_bytes), 0x00020000);
 #pragma unroll
     for (int k = 0; k < EPASS; ++k) {
-      const unsigned o = (unsigned)(((erow + k * RPP) * p.Cout + n0 + ecol) * 4);
+      const unsigned o = (unsigned)(((erow + k * RPP) * p.Cout + n0 + ecol) * EB);
       rres_h[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)o, 0, 0);
-      rres_l[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)(o + 16), 0, 0);
+      if (X3) rres_l[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)(o + 16), 0, 0);
     }
   }
-  if (RES && !X3) {
+  if (RES && !X3 && !BF) {
     const size_t r_bytes = ((size_t)p.M - m0) * p.Cout * 4;
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.res + (size_t)m0 * p.Cout), 0,
@@ -368,7 +406,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   //                        the next tile's first fragments (read right after the barrier)
   // One barrier per step suffices: tile kt+1 is complete in LDS before it, and nobody overwrites
   // buf[kt&1] before the next barrier.  The body is straight-line.
-  const int nk = p.Kp / kBK;
+  const int nk = p.Kp / KC;
   {
     const KStep k0 = kstep(0, nk);
 #pragma unroll
@@ -380,7 +418,33 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
     for (int it = 0; it < NITEMS; ++it) gload_item(k1, 1, it);
   }
   __syncthreads();
-  if constexpr (!X3) {
+  if constexpr (BF) {
+    // plain bf16: four k16-groups of TM*TN MFMAs per K-step.  Groups 0-1 carry the ds_writes of tile kt+1
+    // and the buffer loads of tile kt+2; groups 2-3 run after the barrier and cover the next fragments.
+    frag_load_bf(0, 0);
+    frag_load_bf(0, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const KStep k2 = kstep(kt + 2, nk);
+      frag_load_bf(cur, 2);
+      frag_load_bf(cur, 3);
+      auto inject = [&](int it) {
+        if (it < NITEMS) lstore_item(cur ^ 1, it);
+        else gload_item(k2, kt + 2, it - NITEMS);
+      };
+      mfma_bf(0, 0, NITEMS, inject);
+      mfma_bf(1, NITEMS, NITEMS, inject);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_bf(2, 0, 0, [](int) {});
+      frag_load_bf(cur ^ 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_bf(3, 0, 0, [](int) {});
+      __builtin_amdgcn_sched_barrier(0);
+      frag_load_bf(cur ^ 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (!X3) {
     frag_load(0, 0, 0);
     frag_load(0, 1, 1);
     for (int kt = 0; kt < nk; ++kt) {
@@ -437,11 +501,31 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
 
   // Stores go through a descriptor that ends at row M: rows past the end are dropped by the range
   // check, which keeps the epilogue branch-free (no per-pass wait on earlier stores).
-  const size_t y_bytes = ((size_t)p.M - m0) * p.Cout * 4;
+  const size_t y_bytes = ((size_t)p.M - m0) * p.Cout * EB;
   const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
-      p.y + (size_t)m0 * p.Cout, 0, (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
+      reinterpret_cast<char *>(p.y) + (size_t)m0 * p.Cout * EB, 0,
+      (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
   const float floor_ = p.relu ? 0.f : -INFINITY;  // ReLU as a branch-free clamp
-  if constexpr (!X3) {
+  if constexpr (BF) {
+    const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
+    const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol + 4);
+#pragma unroll
+    for (int k = 0; k < EPASS; ++k) {
+      const int rr = erow + k * RPP;
+      const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cs + rr * CLD + ecol);
+      const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cs + rr * CLD + ecol + 4);
+      float v[8] = {c0[0] + bias0[0], c0[1] + bias0[1], c0[2] + bias0[2], c0[3] + bias0[3],
+                    c1[0] + bias1[0], c1[1] + bias1[1], c1[2] + bias1[2], c1[3] + bias1[3]};
+      if (RES) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += split_elem(rres_h[k], e);
+      }
+      u32x4 o;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) o[w] = pack_bf16(fmaxf(v[2 * w], floor_), fmaxf(v[2 * w + 1], floor_));
+      __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (rr * p.Cout + n0 + ecol) * 2, 0, 0);
+    }
+  } else if constexpr (!X3) {
     const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
 #pragma unroll
     for (int k = 0; k < EPASS; ++k) {
@@ -493,6 +577,8 @@ static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
   const dim3 grid((unsigned)(p.ntm * p.ntn));
   if (p.prec == kPrecBf16x3)
     hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16x3>), grid, dim3(256), 0, s, p);
+  else if (p.prec == kPrecBf16)
+    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16>), grid, dim3(256), 0, s, p);
   else
     hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32>), grid, dim3(256), 0, s, p);
   return hipGetLastError();
@@ -546,12 +632,13 @@ static hipError_t launch_conv_ks(const ConvParams &p, hipStream_t s) {
 }
 
 hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s) {
-  if (p.Cout % 64 != 0 || p.Kp % kBK != 0 || p.M <= 0) return hipErrorInvalidValue;
+  const int kc = p.prec == kPrecBf16 ? 64 : kBK;  // channels per K-step
+  if (p.Cout % 64 != 0 || p.Kp % kc != 0 || p.M <= 0) return hipErrorInvalidValue;
   if ((1 << p.logC4) * 4 != p.C) return hipErrorInvalidValue;
-  if (ks != 7 && p.C % kBK != 0) return hipErrorInvalidValue;
+  if (ks != 7 && p.C % kc != 0) return hipErrorInvalidValue;
   if (p.T > 0 && (ks != 1 || p.stride != 1 || p.N % p.T != 0 || p.fold % 4 != 0)) return hipErrorInvalidValue;
-  if (p.prec != kPrecF32 && p.prec != kPrecBf16x3) return hipErrorInvalidValue;
-  if (p.prec == kPrecBf16x3 && ((p.T > 0 && p.fold % 8 != 0) || (ks == 7 && p.C != 8))) return hipErrorInvalidValue;
+  if (p.prec != kPrecF32 && p.prec != kPrecBf16x3 && p.prec != kPrecBf16) return hipErrorInvalidValue;
+  if (p.prec != kPrecF32 && ((p.T > 0 && p.fold % 8 != 0) || (ks == 7 && p.C != 8))) return hipErrorInvalidValue;
   // 32-bit byte offsets inside a workgroup's rebased window: a tile touches at most
   // BM/(Ho*Wo) + 4 input frames.
   const double frames = 128.0 / ((double)p.Ho * p.Wo) + 4.0;
@@ -566,91 +653,149 @@ hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s) {
   }
 }
 
+// =============================================================================================
+// Storage formats of activations outside the conv kernel.  A "group" is the unit one thread moves:
+//   kPrecF32     4 channels, 16 bytes (4 floats)
+//   kPrecBf16x3  8 channels, 32 bytes [hi x8 | lo x8] (split-bf16)
+//   kPrecBf16    8 channels, 16 bytes (8 bf16)
+// Pointers stay float-typed; gf = group size in 4-byte units.
+// =============================================================================================
+template <int FMT>
+struct Fmt {
+  static constexpr int ch = FMT == kPrecF32 ? 4 : 8;
+  static constexpr int gf = FMT == kPrecBf16x3 ? 8 : 4;
+};
+
+template <int FMT>
+__device__ __forceinline__ void load_group(const float *p, float v[8]) {
+  if (FMT == kPrecF32) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = a[e];
+      v[e + 4] = 0.f;
+    }
+  } else if (FMT == kPrecBf16x3) {
+    const u32x4 h = *reinterpret_cast<const u32x4 *>(p), l = *reinterpret_cast<const u32x4 *>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = split_elem(h, e) + split_elem(l, e);
+  } else {
+    const u32x4 h = *reinterpret_cast<const u32x4 *>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = split_elem(h, e);
+  }
+}
+
+template <int FMT>
+__device__ __forceinline__ void store_group(float *p, const float v[8]) {
+  if (FMT == kPrecF32) {
+    *reinterpret_cast<f32x4 *>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  } else if (FMT == kPrecBf16x3) {
+    u32x4 oh, ol;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned hw, lw;
+      split_pair(v[2 * w], v[2 * w + 1], &hw, &lw);
+      oh[w] = hw;
+      ol[w] = lw;
+    }
+    *reinterpret_cast<u32x4 *>(p) = oh;
+    *reinterpret_cast<u32x4 *>(p + 4) = ol;
+  } else {
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) o[w] = pack_bf16(v[2 * w], v[2 * w + 1]);
+    *reinterpret_cast<u32x4 *>(p) = o;
+  }
+}
+
+static unsigned grid_for(int64_t total, int cap) {
+  const int64_t blocks = (total + 255) / 256;
+  return (unsigned)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap);
+}
+
+#define TSM_DISPATCH_FMT(prec, KERNEL, grid, stream, ...)                                                   \
+  do {                                                                                                      \
+    if ((prec) == kPrecBf16x3)                                                                              \
+      hipLaunchKernelGGL((KERNEL<kPrecBf16x3>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);             \
+    else if ((prec) == kPrecBf16)                                                                           \
+      hipLaunchKernelGGL((KERNEL<kPrecBf16>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);               \
+    else                                                                                                    \
+      hipLaunchKernelGGL((KERNEL<kPrecF32>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                \
+  } while (0)
+
 // ---------------------------------------------------------------------------------------------
-// pack_input: one thread per pixel; planar reads are coalesced along W, the write is one 16-B store.
+// pack_input: [N,3,H,W] or [N,H,W,3] fp32 -> one group per pixel (NHWC4 fp32 / NHWC8 split / NHWC8 bf16,
+// padding channels zero) so every stem tap is whole 16-byte chunks.  One thread per pixel.
 // ---------------------------------------------------------------------------------------------
-template <bool X3>
+template <int FMT>
 __global__ void __launch_bounds__(256) pack_input_kernel(const float *__restrict__ src,
                                                          float *__restrict__ dst, int64_t n_pix_total,
                                                          int64_t hw, int nchw) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix_total; i += stride) {
-    f32x4 v;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (nchw) {
       const int64_t n = i / hw, pix = i - n * hw;
       const float *b = src + n * 3 * hw + pix;
-      v = {b[0], b[hw], b[2 * hw], 0.f};
+      v[0] = b[0];
+      v[1] = b[hw];
+      v[2] = b[2 * hw];
     } else {
       const float *b = src + i * 3;
-      v = {b[0], b[1], b[2], 0.f};
+      v[0] = b[0];
+      v[1] = b[1];
+      v[2] = b[2];
     }
-    if (X3) {  // NHWC8 split: [hi x8 | lo x8], channels 3..7 are zero
-      u32x4 oh = {0u, 0u, 0u, 0u}, ol = {0u, 0u, 0u, 0u};
-      unsigned h0, l0, h1, l1;
-      split_pair(v[0], v[1], &h0, &l0);
-      split_pair(v[2], 0.f, &h1, &l1);
-      oh[0] = h0; oh[1] = h1; ol[0] = l0; ol[1] = l1;
-      *reinterpret_cast<u32x4 *>(dst + i * 8) = oh;
-      *reinterpret_cast<u32x4 *>(dst + i * 8 + 4) = ol;
-    } else {
-      *reinterpret_cast<f32x4 *>(dst + i * 4) = v;
-    }
+    store_group<FMT>(dst + i * Fmt<FMT>::gf, v);
   }
 }
 
 hipError_t launch_pack_input(const float *src, float *dst, int64_t n_frames, int h, int w, int nchw, int prec,
                              hipStream_t s) {
   const int64_t hw = (int64_t)h * w, total = n_frames * hw;
-  const int64_t blocks = (total + 255) / 256;
-  const unsigned grid = (unsigned)(blocks < 4096 ? blocks : 4096);
-  if (prec == kPrecBf16x3)
-    hipLaunchKernelGGL(pack_input_kernel<true>, dim3(grid), dim3(256), 0, s, src, dst, total, hw, nchw);
-  else
-    hipLaunchKernelGGL(pack_input_kernel<false>, dim3(grid), dim3(256), 0, s, src, dst, total, hw, nchw);
+  TSM_DISPATCH_FMT(prec, pack_input_kernel, grid_for(total, 4096), s, src, dst, total, hw, nchw);
   return hipGetLastError();
 }
 
-// fp32 <-> split-bf16, one thread per 8-channel group
-__global__ void __launch_bounds__(256) f32_to_split_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                           int64_t n_groups) {
+// fp32 [n8 * 8] <-> another format, 8 channels per thread
+template <int FMT>
+__global__ void __launch_bounds__(256) from_f32_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                       int64_t n8) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_groups; i += stride) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
     const f32x4 a = *reinterpret_cast<const f32x4 *>(x + i * 8), b = *reinterpret_cast<const f32x4 *>(x + i * 8 + 4);
-    u32x4 oh, ol;
-    unsigned h, l;
-    split_pair(a[0], a[1], &h, &l); oh[0] = h; ol[0] = l;
-    split_pair(a[2], a[3], &h, &l); oh[1] = h; ol[1] = l;
-    split_pair(b[0], b[1], &h, &l); oh[2] = h; ol[2] = l;
-    split_pair(b[2], b[3], &h, &l); oh[3] = h; ol[3] = l;
-    *reinterpret_cast<u32x4 *>(y + i * 8) = oh;
-    *reinterpret_cast<u32x4 *>(y + i * 8 + 4) = ol;
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    store_group<FMT>(y + i * Fmt<FMT>::gf, v);
   }
 }
-__global__ void __launch_bounds__(256) split_to_f32_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                           int64_t n_groups) {
+template <int FMT>
+__global__ void __launch_bounds__(256) to_f32_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                     int64_t n8) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_groups; i += stride) {
-    const u32x4 h = *reinterpret_cast<const u32x4 *>(x + i * 8), l = *reinterpret_cast<const u32x4 *>(x + i * 8 + 4);
-    f32x4 a, b;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      a[e] = split_elem(h, e) + split_elem(l, e);
-      b[e] = split_elem(h, e + 4) + split_elem(l, e + 4);
-    }
-    *reinterpret_cast<f32x4 *>(y + i * 8) = a;
-    *reinterpret_cast<f32x4 *>(y + i * 8 + 4) = b;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    float v[8];
+    load_group<FMT>(x + i * Fmt<FMT>::gf, v);
+    *reinterpret_cast<f32x4 *>(y + i * 8) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4 *>(y + i * 8 + 4) = f32x4{v[4], v[5], v[6], v[7]};
   }
 }
-static unsigned grid_for(int64_t total, int cap) {
-  const int64_t blocks = (total + 255) / 256;
-  return (unsigned)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap);
-}
-hipError_t launch_f32_to_split(const float *x, float *y, int64_t n_groups, hipStream_t s) {
-  hipLaunchKernelGGL(f32_to_split_kernel, dim3(grid_for(n_groups, 8192)), dim3(256), 0, s, x, y, n_groups);
+hipError_t launch_from_f32(const float *x, float *y, int64_t n8, int prec, hipStream_t s) {
+  if (prec == kPrecBf16x3)
+    hipLaunchKernelGGL(from_f32_kernel<kPrecBf16x3>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
+  else if (prec == kPrecBf16)
+    hipLaunchKernelGGL(from_f32_kernel<kPrecBf16>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
+  else
+    return hipErrorInvalidValue;
   return hipGetLastError();
 }
-hipError_t launch_split_to_f32(const float *x, float *y, int64_t n_groups, hipStream_t s) {
-  hipLaunchKernelGGL(split_to_f32_kernel, dim3(grid_for(n_groups, 8192)), dim3(256), 0, s, x, y, n_groups);
+hipError_t launch_to_f32(const float *x, float *y, int64_t n8, int prec, hipStream_t s) {
+  if (prec == kPrecBf16x3)
+    hipLaunchKernelGGL(to_f32_kernel<kPrecBf16x3>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
+  else if (prec == kPrecBf16)
+    hipLaunchKernelGGL(to_f32_kernel<kPrecBf16>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
+  else
+    return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
@@ -680,7 +825,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreprocParams p) 
     const float h1 = fy - (float)y0, h0 = 1.f - h1, w1 = fx - (float)x0, w0 = 1.f - w1;
     const T *b = src + f * (int64_t)p.h * p.w * 3;
     const T *r0 = b + (int64_t)y0 * p.w * 3, *r1 = b + (int64_t)y1 * p.w * 3;
-    float v[4];
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const float p00 = (float)r0[x0 * 3 + c], p01 = (float)r0[x1 * 3 + c];
@@ -688,22 +833,17 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreprocParams p) 
       const float t = h0 * (w0 * p00 + w1 * p01) + h1 * (w0 * p10 + w1 * p11);
       v[c] = (t * p.pre_scale - mean[c]) / stdv[c];
     }
-    v[3] = 0.f;
     if (p.out_mode == 1) {
       float *o = p.dst + f * 3 * (int64_t)p.crop * p.crop + (int64_t)cy * p.crop + cx;
       o[0] = v[0];
       o[(int64_t)p.crop * p.crop] = v[1];
       o[2 * (int64_t)p.crop * p.crop] = v[2];
     } else if (p.out_mode == 2) {
-      u32x4 oh = {0u, 0u, 0u, 0u}, ol = {0u, 0u, 0u, 0u};
-      unsigned h0, l0, h1, l1;
-      split_pair(v[0], v[1], &h0, &l0);
-      split_pair(v[2], 0.f, &h1, &l1);
-      oh[0] = h0; oh[1] = h1; ol[0] = l0; ol[1] = l1;
-      *reinterpret_cast<u32x4 *>(p.dst + i * 8) = oh;
-      *reinterpret_cast<u32x4 *>(p.dst + i * 8 + 4) = ol;
+      store_group<kPrecBf16x3>(p.dst + i * 8, v);
+    } else if (p.out_mode == 3) {
+      store_group<kPrecBf16>(p.dst + i * 4, v);
     } else {
-      *reinterpret_cast<f32x4 *>(p.dst + i * 4) = f32x4{v[0], v[1], v[2], v[3]};
+      store_group<kPrecF32>(p.dst + i * 4, v);
     }
   }
 }
@@ -713,8 +853,7 @@ hipError_t launch_preprocess(const PreprocParams &p, hipStream_t s) {
       p.left + p.crop > p.nw)
     return hipErrorInvalidValue;
   const int64_t total = (int64_t)p.n * p.crop * p.crop;
-  const int64_t blocks = (total + 255) / 256;
-  const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+  const unsigned grid = grid_for(total, 8192);
   if (p.src_is_u8)
     hipLaunchKernelGGL(preprocess_kernel<unsigned char>, dim3(grid), dim3(256), 0, s, p);
   else
@@ -723,14 +862,13 @@ hipError_t launch_preprocess(const PreprocParams &p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// maxpool 3x3 stride 2 pad 1, NHWC; one thread per (output pixel, 4 channels).
+// maxpool 3x3 stride 2 pad 1, NHWC; one thread per (output pixel, channel group).
 // ---------------------------------------------------------------------------------------------
-template <bool X3>
+template <int FMT>
 __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float *__restrict__ x,
                                                            float *__restrict__ y, int n, int hi, int wi,
                                                            int ho, int wo, int cg) {
-  // cg = channel groups per pixel: 4 floats (fp32) or one 32-byte split group of 8 channels
-  constexpr int GF = X3 ? 8 : 4;  // floats-worth of storage per group
+  constexpr int GF = Fmt<FMT>::gf;
   const int64_t total = (int64_t)n * ho * wo * cg;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -751,51 +889,29 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const float *__restri
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = ox * 2 - 1 + kx;
         if ((unsigned)ix >= (unsigned)wi) continue;
-        const float *src = x + (((f * hi + iy) * wi + ix) * cg + g) * GF;
-        if (X3) {
-          const u32x4 h = *reinterpret_cast<const u32x4 *>(src), l = *reinterpret_cast<const u32x4 *>(src + 4);
+        float v[8];
+        load_group<FMT>(x + (((f * hi + iy) * wi + ix) * cg + g) * GF, v);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], split_elem(h, e) + split_elem(l, e));
-        } else {
-          const f32x4 v = *reinterpret_cast<const f32x4 *>(src);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
-        }
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
       }
     }
-    if (X3) {
-      u32x4 oh, ol;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        unsigned hw, lw;
-        split_pair(m[2 * w], m[2 * w + 1], &hw, &lw);
-        oh[w] = hw;
-        ol[w] = lw;
-      }
-      *reinterpret_cast<u32x4 *>(y + i * 8) = oh;
-      *reinterpret_cast<u32x4 *>(y + i * 8 + 4) = ol;
-    } else {
-      *reinterpret_cast<f32x4 *>(y + i * 4) = f32x4{m[0], m[1], m[2], m[3]};
-    }
+    store_group<FMT>(y + i * GF, m);
   }
 }
 
 hipError_t launch_maxpool3x3s2(const float *x, float *y, int n, int hi, int wi, int c, int prec, hipStream_t s) {
-  const bool x3 = prec == kPrecBf16x3;
-  if (c % (x3 ? 8 : 4) != 0) return hipErrorInvalidValue;
+  const int gch = prec == kPrecF32 ? 4 : 8;
+  if (c % gch != 0) return hipErrorInvalidValue;
   const int ho = (hi + 2 - 3) / 2 + 1, wo = (wi + 2 - 3) / 2 + 1;
-  const int cg = c / (x3 ? 8 : 4);
+  const int cg = c / gch;
   const int64_t total = (int64_t)n * ho * wo * cg;
-  if (x3)
-    hipLaunchKernelGGL(maxpool3x3s2_kernel<true>, dim3(grid_for(total, 8192)), dim3(256), 0, s, x, y, n, hi, wi, ho, wo, cg);
-  else
-    hipLaunchKernelGGL(maxpool3x3s2_kernel<false>, dim3(grid_for(total, 8192)), dim3(256), 0, s, x, y, n, hi, wi, ho, wo, cg);
+  TSM_DISPATCH_FMT(prec, maxpool3x3s2_kernel, grid_for(total, 8192), s, x, y, n, hi, wi, ho, wo, cg);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stand-alone temporal shift (NHWC).  One thread per 16-B channel quad; fold % 4 == 0 so a quad
-// never straddles a fold boundary.  tsm.py:35-50.
+// Stand-alone temporal shift (NHWC fp32).  One thread per 16-B channel quad; fold % 4 == 0 so a quad
+// never straddles a fold boundary.  tsm.py:35-50.  (The forward uses the conv kernel's fused loader.)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) temporal_shift_kernel(const float *__restrict__ x,
                                                              float *__restrict__ y, int64_t n_frames,
@@ -819,53 +935,36 @@ hipError_t launch_temporal_shift(const float *x, float *y, int64_t n_frames, int
                                  int c, int fold, hipStream_t s) {
   if (c % 4 != 0 || fold % 4 != 0 || n_segment <= 0 || n_frames % n_segment != 0) return hipErrorInvalidValue;
   const int64_t total = n_frames * hw * (c / 4);
-  const int64_t blocks = (total + 255) / 256;
-  const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
-  hipLaunchKernelGGL(temporal_shift_kernel, dim3(grid), dim3(256), 0, s, x, y, n_frames, n_segment, hw,
-                     c / 4, fold / 4);
+  hipLaunchKernelGGL(temporal_shift_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, x, y, n_frames,
+                     n_segment, hw, c / 4, fold / 4);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
 // Head.  logits[b] = fc( mean_t mean_hw feat[b,t,hw,:] ) + bias  (avg-pool, FC and the segment mean
 // are all linear, so pooling first is exact up to fp32 summation order).  tsm.py:411-419.
-//   head_pool: grid (n_frames, ...): per-frame average pool into pooled[n_frames, c].
+//   head_pool: grid (n_frames, ...): per-frame average pool into pooled[n_frames, c] (fp32);
+//              one thread per channel group, rows streamed with 16-byte loads.
 //   head_fc  : grid n_clips: mean over the clip's frames, one wave per class round-robin.
 // ---------------------------------------------------------------------------------------------
-// head_pool: fp32 -> thread = one channel (rows streamed coalesced); split -> thread = one 32-byte group of
-// 8 channels (two 16-byte loads per row).  grid (n_clips, ceil(threads / 256)).
-template <bool X3>
+template <int FMT>
 __global__ void __launch_bounds__(256) head_pool_kernel(const float *__restrict__ feat,
                                                         float *__restrict__ pooled, int rows, int c) {
+  constexpr int GF = Fmt<FMT>::gf, GC = Fmt<FMT>::ch;
   const int b = blockIdx.x;
   const int t = blockIdx.y * 256 + threadIdx.x;
-  if (X3) {
-    if (t >= c / 8) return;
-    const float *src = feat + (size_t)b * rows * c + (size_t)t * 8;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < rows; ++r) {
-      const u32x4 h = *reinterpret_cast<const u32x4 *>(src + (size_t)r * c);
-      const u32x4 l = *reinterpret_cast<const u32x4 *>(src + (size_t)r * c + 4);
+  const int cg = c / GC;
+  if (t >= cg) return;
+  const float *src = feat + ((size_t)b * rows * cg + t) * GF;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < rows; ++r) {
+    float v[8];
+    load_group<FMT>(src + (size_t)r * cg * GF, v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += split_elem(h, e) + split_elem(l, e);
-    }
+    for (int e = 0; e < 8; ++e) acc[e] += v[e];
+  }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) pooled[(size_t)b * c + t * 8 + e] = acc[e] / (float)rows;
-    return;
-  }
-  const int ch = t;
-  if (ch >= c) return;
-  const float *src = feat + (size_t)b * rows * c + ch;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int r = 0;
-  for (; r + 4 <= rows; r += 4) {
-    s0 += src[(size_t)(r + 0) * c];
-    s1 += src[(size_t)(r + 1) * c];
-    s2 += src[(size_t)(r + 2) * c];
-    s3 += src[(size_t)(r + 3) * c];
-  }
-  for (; r < rows; ++r) s0 += src[(size_t)r * c];
-  pooled[(size_t)b * c + ch] = ((s0 + s1) + (s2 + s3)) / (float)rows;
+  for (int e = 0; e < GC; ++e) pooled[(size_t)b * c + t * GC + e] = acc[e] / (float)rows;
 }
 
 __global__ void __launch_bounds__(256) head_fc_kernel(const float *__restrict__ pooled,
@@ -893,15 +992,15 @@ __global__ void __launch_bounds__(256) head_fc_kernel(const float *__restrict__ 
 hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, float *pooled,
                        float *logits, int n_clips, int n_segment, int hw, int c, int num_class, int prec,
                        hipStream_t s) {
-  if (n_clips <= 0 || c <= 0) return hipErrorInvalidValue;
-  // stage 1: one workgroup row per FRAME (n_clips * n_segment of them) so the whole chip streams the
-  // feature map; stage 2 averages the frames of a clip and applies the classifier.
+  if (n_clips <= 0 || c <= 0 || c % 8 != 0) return hipErrorInvalidValue;
+  const int cg = c / (prec == kPrecF32 ? 4 : 8);
+  const dim3 grid(n_clips * n_segment, (cg + 255) / 256);
   if (prec == kPrecBf16x3)
-    hipLaunchKernelGGL(head_pool_kernel<true>, dim3(n_clips * n_segment, (c / 8 + 255) / 256), dim3(256), 0, s, feat,
-                       pooled, hw, c);
+    hipLaunchKernelGGL(head_pool_kernel<kPrecBf16x3>, grid, dim3(256), 0, s, feat, pooled, hw, c);
+  else if (prec == kPrecBf16)
+    hipLaunchKernelGGL(head_pool_kernel<kPrecBf16>, grid, dim3(256), 0, s, feat, pooled, hw, c);
   else
-    hipLaunchKernelGGL(head_pool_kernel<false>, dim3(n_clips * n_segment, (c + 255) / 256), dim3(256), 0, s, feat,
-                       pooled, hw, c);
+    hipLaunchKernelGGL(head_pool_kernel<kPrecF32>, grid, dim3(256), 0, s, feat, pooled, hw, c);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(head_fc_kernel, dim3(n_clips), dim3(256), 0, s, pooled, fc_w, fc_b, logits, c,

@@ -53,7 +53,8 @@ class TsmEngine:
             raise ValueError(f'dtype must be one of {sorted(_lib.DTYPES)}, got {dtype!r}')
         self.dtype = dtype
         # layout tsm_preprocess must write for this engine to consume frames in place
-        self.packed_layout = _lib.LAYOUT_NTHWC8S if dtype == 'bf16x3' else _lib.LAYOUT_NTHWC4
+        self.packed_layout = {'f32': _lib.LAYOUT_NTHWC4, 'bf16x3': _lib.LAYOUT_NTHWC8S,
+                              'bf16': _lib.LAYOUT_NTHWC8B}[dtype]
         cfg = _lib.TsmConfig(C.sizeof(_lib.TsmConfig), num_class, num_segments, height, width, shift_div,
                              1 if is_shift else 0, max_clips, device, _lib.DTYPES[dtype])
         _lib.check(self._lib.tsm_create(C.byref(cfg), C.byref(self._h)))
@@ -320,6 +321,7 @@ def preprocess_frames(frames, resize: int = 256, crop: int = 224, scale_255: boo
     if layout is None:
         layout = _lib.LAYOUT_NTHWC4 if packed else _lib.LAYOUT_NTCHW
     shape = {_lib.LAYOUT_NTHWC4: (n, crop, crop, 4), _lib.LAYOUT_NTHWC8S: (n, crop, crop, 8),
+             _lib.LAYOUT_NTHWC8B: (n, crop, crop, 4),      # 8 bf16 = 16 bytes = 4 float slots per pixel
              _lib.LAYOUT_NTCHW: (n, 3, crop, crop)}[layout]
     out = torch.empty(shape, dtype=torch.float32, device=frames.device)
     _lib.check(_lib.load().tsm_preprocess(frames.data_ptr(), pixel, n, h, w, out.data_ptr(), layout, resize, crop,
