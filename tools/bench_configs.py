@@ -1,0 +1,119 @@
+"""Measure the BASELINE.json configurations that are not bench.py's headline, on ONE MI355X.
+
+  config 3  pull_up-shaped stream: 1080 frames of 360x206 uint8 -> 135 clips, end to end
+            (H2D of the uint8 frames, fused HIP transform, engine, softmax/threshold, pred_to_count),
+            plus the streaming variant: latency of one 8-frame window at batch 1
+  config 4  RepCount-val-shaped workload: 100 videos, >= 10 021 clips in total, end to end per video
+            (the 8-GPU sharding of this config is covered by tests/test_distributed_cpu.py; here: 1 GPU)
+  config 5  T=16, 256x256, 64 clips per GPU, TSM_DTYPE_BF16 (and the exact-f32 mode on the same shape)
+
+    python tools/bench_configs.py [--dtype f32|bf16x3] > gpurun_out/configs.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from workoutdetector_amd import inference_count as ic  # noqa: E402
+from workoutdetector_amd.counting import pred_to_count, scores_to_preds  # noqa: E402
+from workoutdetector_amd.engine import TsmEngine  # noqa: E402
+from workoutdetector_amd.transform import build_test_transform  # noqa: E402
+from workoutdetector_amd.weights import make_state_dict  # noqa: E402
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def config3(eng, reps=5):
+    rng = np.random.default_rng(0)
+    vid = torch.from_numpy(rng.integers(0, 256, size=(1080, 360, 206, 3), dtype=np.uint8))
+    tf = build_test_transform(False)
+    ic.video_clip_logits(eng, vid, tf)          # warm-up (tile autotune for 32- and 7-clip batches)
+    sync()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        logits = ic.video_clip_logits(eng, vid, tf, batch_clips=32)
+        states = scores_to_preds(logits.tolist())
+        count, _ = pred_to_count(states, 8)
+        ts.append(time.perf_counter() - t0)
+    n = logits.shape[0]
+    # streaming: one non-overlapping 8-frame window at a time (batch 1), frames already on the host
+    win = vid[:8]
+    lat = []
+    for i in range(12):
+        t0 = time.perf_counter()
+        ic.inference_video(eng, win.float(), transform=tf)
+        lat.append(time.perf_counter() - t0)
+    lat = sorted(lat[2:])
+    return {'clips': int(n), 'end_to_end_s_median': float(np.median(ts)), 'clips_per_s': n / float(np.median(ts)),
+            'count': int(count), 'stream_window_latency_ms_median': 1e3 * lat[len(lat) // 2],
+            'note': 'end to end = uint8 frames on the host -> H2D -> tsm_preprocess -> tsm_forward (batches of 32) -> '
+                    'D2H logits -> softmax/threshold -> pred_to_count; window latency = reference-style '
+                    'inference_video (torch transform + host round trip) at batch 1'}
+
+
+def config4(eng, total_clips=10021, n_videos=100):
+    rng = np.random.default_rng(0)
+    # clip counts per video: lognormal-ish spread with the annotated lower bound as the total
+    w = rng.lognormal(0.0, 0.6, n_videos)
+    clips = np.maximum(8, np.round(w / w.sum() * total_clips)).astype(int)
+    clips[-1] += max(0, total_clips - int(clips.sum()))
+    tf = build_test_transform(False)
+    gen = torch.Generator().manual_seed(0)
+    ic.video_clip_logits(eng, torch.randint(0, 256, (64, 360, 206, 3), dtype=torch.uint8, generator=gen), tf)
+    sync()
+    t_total, counts = 0.0, []
+    for c in clips:
+        frames = int(c) * 8 - int(rng.integers(0, 8))
+        vid = torch.randint(0, 256, (frames, 360, 206, 3), dtype=torch.uint8, generator=gen)   # not timed: synthetic decode
+        t0 = time.perf_counter()
+        logits = ic.video_clip_logits(eng, vid, tf, batch_clips=32)
+        counts.append(pred_to_count(scores_to_preds(logits.tolist()), 8)[0])
+        t_total += time.perf_counter() - t0
+    n = int(sum(len(ic.clip_starts(int(c) * 8)) for c in clips))
+    return {'videos': n_videos, 'clips': n, 'end_to_end_s': t_total, 'clips_per_s': n / t_total,
+            'note': 'per video: H2D of uint8 frames, fused transform, engine in batches of 32 (ragged last batch), '
+                    'counter; synthetic frame generation is outside the timed region (no decoder offline)'}
+
+
+def config5(dtype, steps=10, warmup=3, batch=64):
+    eng = TsmEngine(num_segments=16, height=256, width=256, max_clips=batch, state_dict=make_state_dict(0, 12), dtype=dtype)
+    x = torch.randn(batch, 16, 3, 256, 256, device='cuda')
+    out = torch.empty(batch, 12, device='cuda')
+    for _ in range(warmup):
+        eng.forward_device(x, out=out)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward_device(x, out=out)
+    sync()
+    dt = (time.perf_counter() - t0) / steps
+    eng.close()
+    gflop = 170.826
+    return {'dtype': dtype, 'clips_per_gpu': batch, 'ms_per_step': 1e3 * dt, 'clips_per_s': batch / dt,
+            'algorithmic_tflops': gflop * batch / dt / 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--dtype', default='f32')
+    args = ap.parse_args()
+    eng = TsmEngine(max_clips=32, state_dict=make_state_dict(0, 12), dtype=args.dtype)
+    res = {'engine_dtype': args.dtype, 'config3': config3(eng), 'config4': config4(eng)}
+    eng.close()
+    res['config5_bf16'] = config5('bf16')
+    res['config5_f32'] = config5('f32', steps=4, warmup=2)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == '__main__':
+    main()

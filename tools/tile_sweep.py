@@ -44,6 +44,6 @@ names = list(res['default'])
 print(f"{'layer':24s}" + ''.join(f'{t:>10s}' for t in res))
 for n in names:
     print(f'{n:24s}' + ''.join(f'{res[t][n] * 1e3:10.1f}' for t in res))
-print(f"{'total ms':24s}" + ''.join(f'{sum(res[t].values()):10.3f}' for t in res))
-best = sum(min(res[t][n] for t in res) for n in names)
+print(f"{'total ms':24s}" + ''.join(f'{sum(max(0.0, v) for v in res[t].values()):10.3f}' for t in res))
+best = sum(max(0.0, min(res[t][n] for t in res)) for n in names)
 print('best-of per layer total ms:', round(best, 3))

@@ -22,7 +22,14 @@ struct ConvParams {
   int fold;  // C / shift_div
   int ntm, ntn;
   int tile;  // 0 = heuristic, else a ConvTile chosen by the engine's autotuner
-  int prec;  // kPrecF32 | kPrecBf16x3 (storage format of x, w, res, y and the MFMA used)
+  int prec;  // ConvPrec: storage format of x, w, res, y and the MFMA used
+  // Second A source, concatenated along K behind the first (1x1 convs only): fuses
+  //   y = act( conv1x1(x, W) + conv1x1_strided(x2, W2) + bias )
+  // i.e. Bottleneck.conv3 + the downsample branch of a stage's first block in one GEMM, so the
+  // identity tensor is never written or read.  x2 == nullptr: single source.
+  const float *x2;
+  int C2, Hi2, Wi2, stride2;
+  int K1;    // channels of the first source (its K extent); Kp = K1 + C2
 };
 
 enum ConvPrec { kPrecF32 = 0, kPrecBf16x3 = 1, kPrecBf16 = 2 };

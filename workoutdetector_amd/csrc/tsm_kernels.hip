@@ -83,9 +83,10 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 //                32-byte group [hi x8 | lo x8] (same 4 bytes per element, same byte offsets as fp32, so the
 //                loader is shared).  a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32
 //                accumulation: relative error ~2^-17 per product, three MFMAs at 16x the fp32-MFMA rate.
-template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC>
+template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false>
 __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
+  static_assert(!DUAL || (KS == 1 && !SHIFT && !RES), "K-concatenated second source: plain 1x1 convs only");
   constexpr bool X3 = PREC == kPrecBf16x3;
   constexpr bool BF = PREC == kPrecBf16;   // plain bf16 storage, one bf16 MFMA per product (config 5)
   constexpr int EB = BF ? 2 : 4;           // bytes per stored element
@@ -127,12 +128,20 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
       const_cast<char *>(reinterpret_cast<const char *>(p.w) + (size_t)n0 * p.Kp * EB), 0, BN * p.Kp * EB,
       0x00020000);
 
+  // second A source (DUAL): same output pixels, its own channel count / spatial size / stride
+  const size_t frame_elems2 = DUAL ? (size_t)p.Hi2 * p.Wi2 * p.C2 : 0;
+  const size_t a2_bytes = DUAL ? ((size_t)p.N - n_first) * frame_elems2 * EB : 0;
+  const __amdgpu_buffer_rsrc_t rsrcA2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(reinterpret_cast<const char *>(DUAL ? p.x2 : p.x) + (size_t)n_first * frame_elems2 * EB), 0,
+      (int)(a2_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : a2_bytes), 0x00020000);
+
   // ---- per-thread loader state: 8 threads per 32-float row, 32 rows per pass -------------------
   const int chunk = tid & 7, lrow = tid >> 3;
   const int frame_bytes = (int)(frame_elems * EB);
   unsigned a_off[APASS];                       // byte offset of (row, tap 0, this thread's chunk)
   unsigned a_offp[SHIFT ? APASS : 1], a_offm[SHIFT ? APASS : 1];
   unsigned a_mask[KS == 3 ? APASS : 1];
+  unsigned a_off2[DUAL ? APASS : 1];
   int a_iy[KS == 7 ? APASS : 1], a_ix[KS == 7 ? APASS : 1];
 #pragma unroll
   for (int pp = 0; pp < APASS; ++pp) {
@@ -150,6 +159,10 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
     } else {
       const int base = (n - frame0) * frame_bytes + (iy0 * p.Wi + ix0) * p.C * EB + chunk * 16;
       a_off[pp] = (KS == 1 && !ok) ? kInvalid : (unsigned)base;
+      if (DUAL)
+        a_off2[pp] = ok ? (unsigned)((n - n_first) * (int)(frame_elems2 * EB) +
+                                     (oy * p.stride2 * p.Wi2 + ox * p.stride2) * p.C2 * EB + chunk * 16)
+                        : kInvalid;
       if (KS == 3) {
         unsigned mask = 0;
 #pragma unroll
@@ -172,6 +185,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   for (int pp = 0; pp < BPASS; ++pp) b_off[pp] = (unsigned)((lrow + 32 * pp) * p.Kp * EB + chunk * 16);
 
   f32x4 ra[APASS], rb[BPASS];
+  const int nk1 = DUAL ? p.K1 / KC : 0;
 
   // Loader work is cut into NITEMS = APASS + BPASS single-instruction items (one 16-B buffer load or
   // one ds_write_b128 each) so the main loop can drop one item between consecutive MFMAs.
@@ -215,7 +229,14 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
       if (KS == 1) {
         unsigned off = a_off[pp];
         if (SHIFT) off = (a_offp[pp] & k.mp) | (a_offm[pp] & k.mm) | (a_off[pp] & k.m0);
-        ra[pp] = buf_load4(rsrcA, off | k.dead, k.kbytes);
+        if (DUAL) {
+          // K-steps [0, nk1) come from the first source, the rest from the second (wave-uniform choice)
+          const bool second = kt >= nk1;
+          ra[pp] = buf_load4(second ? rsrcA2 : rsrcA, (second ? a_off2[pp] : off) | k.dead,
+                             second ? k.kbytes - (unsigned)nk1 * 128u : k.kbytes);
+        } else {
+          ra[pp] = buf_load4(rsrcA, off | k.dead, k.kbytes);
+        }
       } else if (KS == 3) {
         ra[pp] = buf_load4(rsrcA, (((a_mask[pp] >> k.tap) & 1u) ? a_off[pp] + (unsigned)k.tap_off : kInvalid) | k.dead, 0);
       } else {
@@ -575,6 +596,17 @@ static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
   p.ntm = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   const dim3 grid((unsigned)(p.ntm * p.ntn));
+  if constexpr (KS == 1 && !SHIFT && !RES) {
+    if (p.x2) {
+      if (p.prec == kPrecBf16x3)
+        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecBf16x3, true>), grid, dim3(256), 0, s, p);
+      else if (p.prec == kPrecBf16)
+        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecBf16, true>), grid, dim3(256), 0, s, p);
+      else
+        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecF32, true>), grid, dim3(256), 0, s, p);
+      return hipGetLastError();
+    }
+  }
   if (p.prec == kPrecBf16x3)
     hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16x3>), grid, dim3(256), 0, s, p);
   else if (p.prec == kPrecBf16)
@@ -637,6 +669,8 @@ hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s) {
   if ((1 << p.logC4) * 4 != p.C) return hipErrorInvalidValue;
   if (ks != 7 && p.C % kc != 0) return hipErrorInvalidValue;
   if (p.T > 0 && (ks != 1 || p.stride != 1 || p.N % p.T != 0 || p.fold % 4 != 0)) return hipErrorInvalidValue;
+  if (p.x2 && (ks != 1 || p.T > 0 || p.res || p.K1 % kc != 0 || p.C2 % kc != 0 || p.K1 + p.C2 != p.Kp || p.K1 != p.C))
+    return hipErrorInvalidValue;
   if (p.prec != kPrecF32 && p.prec != kPrecBf16x3 && p.prec != kPrecBf16) return hipErrorInvalidValue;
   if (p.prec != kPrecF32 && ((p.T > 0 && p.fold % 8 != 0) || (ks == 7 && p.C != 8))) return hipErrorInvalidValue;
   // 32-bit byte offsets inside a workgroup's rebased window: a tile touches at most

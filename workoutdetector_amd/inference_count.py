@@ -144,14 +144,14 @@ def video_clip_logits(model, video_thwc_u8: torch.Tensor, transform: TestTransfo
     out = []
     for b in range(0, idx.shape[0], batch_clips):
         clips = frames[idx[b:b + batch_clips]]                                # [b, 8, 3, 224, 224] / [b, 8, 224, 224, 4]
-        if hip_transform:
-            out.append(model.forward_device(clips.contiguous(), layout=packed_layout).cpu())
+        if hip_transform:       # device logits are collected and copied to the host once per video
+            out.append(model.forward_device(clips.contiguous(), layout=packed_layout))
         elif dev is not None:
-            out.append(model.forward_device(clips.contiguous()).cpu())
+            out.append(model.forward_device(clips.contiguous()))
         else:
             name = model.get_inputs()[0].name
             out.append(torch.from_numpy(np.asarray(model.run(None, {name: clips.cpu().numpy()})[0])))
-    return torch.cat(out, dim=0).to(torch.float32)
+    return torch.cat(out, dim=0).to(torch.float32).cpu()
 
 
 def _gathered_video_logits(model, vid: torch.Tensor, transform: TestTransform, batch_clips: int) -> torch.Tensor:
