@@ -8,12 +8,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
-import sys, json, torch
+import sys, json, torch, os
 sys.path.insert(0, %r)
 from workoutdetector_amd.engine import TsmEngine
 from workoutdetector_amd.weights import make_state_dict
-B = 32
-import os
+B = int(os.environ.get('TSM_SWEEP_BATCH', '32'))
 eng = TsmEngine(max_clips=B, state_dict=make_state_dict(0, 12), dtype=os.environ.get('TSM_SWEEP_DTYPE', 'f32'))
 x = torch.randn(B, 8, 3, 224, 224, device='cuda')
 for _ in range(3): eng.forward_device(x)

@@ -979,7 +979,7 @@ hipError_t launch_temporal_shift(const float *x, float *y, int64_t n_frames, int
 // are all linear, so pooling first is exact up to fp32 summation order).  tsm.py:411-419.
 //   head_pool: grid (n_frames, ...): per-frame average pool into pooled[n_frames, c] (fp32);
 //              one thread per channel group, rows streamed with 16-byte loads.
-//   head_fc  : grid n_clips: mean over the clip's frames, one wave per class round-robin.
+//   head_fc  : grid (n_clips, num_class) x 64 lanes: mean over the clip's frames, dot with one class row.
 // ---------------------------------------------------------------------------------------------
 template <int FMT>
 __global__ void __launch_bounds__(256) head_pool_kernel(const float *__restrict__ feat,
@@ -1001,26 +1001,28 @@ __global__ void __launch_bounds__(256) head_pool_kernel(const float *__restrict_
   for (int e = 0; e < GC; ++e) pooled[(size_t)b * c + t * GC + e] = acc[e] / (float)rows;
 }
 
-__global__ void __launch_bounds__(256) head_fc_kernel(const float *__restrict__ pooled,
-                                                      const float *__restrict__ fc_w,
-                                                      const float *__restrict__ fc_b,
-                                                      float *__restrict__ logits, int c, int num_class,
-                                                      int n_segment) {
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// one 64-lane workgroup per (clip, class): every lane streams its share of the 2048 channels over the
+// clip's T pooled frames (independent loads), then a wave reduction
+__global__ void __launch_bounds__(64) head_fc_kernel(const float *__restrict__ pooled,
+                                                     const float *__restrict__ fc_w,
+                                                     const float *__restrict__ fc_b,
+                                                     float *__restrict__ logits, int c, int num_class,
+                                                     int n_segment) {
+  const int b = blockIdx.x, cls = blockIdx.y;
+  const int lane = threadIdx.x;
   const float *pv = pooled + (size_t)b * n_segment * c;  // per-frame pooled features of this clip
-  for (int cls = wave; cls < num_class; cls += 4) {
-    const float *wv = fc_w + (size_t)cls * c;
-    float s = 0.f;
-    for (int k = lane; k < c; k += 64) {
-      float f = 0.f;
-      for (int t = 0; t < n_segment; ++t) f += pv[(size_t)t * c + k];
-      s += (f / (float)n_segment) * wv[k];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) logits[(size_t)b * num_class + cls] = s + fc_b[cls];
+  const float *wv = fc_w + (size_t)cls * c;
+  float s = 0.f;
+  for (int k = lane * 4; k < c; k += 256) {
+    f32x4 f = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < n_segment; ++t) f += *reinterpret_cast<const f32x4 *>(pv + (size_t)t * c + k);
+    const f32x4 w = *reinterpret_cast<const f32x4 *>(wv + k);
+    s += (f[0] * w[0] + f[1] * w[1]) + (f[2] * w[2] + f[3] * w[3]);
   }
+  s /= (float)n_segment;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) logits[(size_t)b * num_class + cls] = s + fc_b[cls];
 }
 
 hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, float *pooled,
@@ -1037,7 +1039,7 @@ hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, 
     hipLaunchKernelGGL(head_pool_kernel<kPrecF32>, grid, dim3(256), 0, s, feat, pooled, hw, c);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(head_fc_kernel, dim3(n_clips), dim3(256), 0, s, pooled, fc_w, fc_b, logits, c,
+  hipLaunchKernelGGL(head_fc_kernel, dim3(n_clips, num_class), dim3(64), 0, s, pooled, fc_w, fc_b, logits, c,
                      num_class, n_segment);
   return hipGetLastError();
 }
