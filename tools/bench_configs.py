@@ -71,18 +71,24 @@ def config4(eng, total_clips=10021, n_videos=100):
     gen = torch.Generator().manual_seed(0)
     ic.video_clip_logits(eng, torch.randint(0, 256, (64, 360, 206, 3), dtype=torch.uint8, generator=gen), tf)
     sync()
-    t_total, counts = 0.0, []
-    for c in clips:
-        frames = int(c) * 8 - int(rng.integers(0, 8))
-        vid = torch.randint(0, 256, (frames, 360, 206, 3), dtype=torch.uint8, generator=gen)   # not timed: synthetic decode
+    # synthetic "decoded" videos are made up front (no decoder offline); in batches so host memory stays bounded
+    n, t_total, counts = 0, 0.0, []
+    for g0 in range(0, n_videos, 20):
+        vids = []
+        for c in clips[g0:g0 + 20]:
+            frames = int(c) * 8 - int(rng.integers(0, 8))
+            vids.append(torch.randint(0, 256, (frames, 360, 206, 3), dtype=torch.uint8, generator=gen))
+        sync()
         t0 = time.perf_counter()
-        logits = ic.video_clip_logits(eng, vid, tf, batch_clips=32)
-        counts.append(pred_to_count(scores_to_preds(logits.tolist()), 8)[0])
+        for _, st in ic.prefetch_staged(eng, enumerate(vids)):
+            logits = ic.staged_clip_logits(eng, st, tf, batch_clips=32)
+            counts.append(pred_to_count(scores_to_preds(logits.tolist()), 8)[0])
+            n += logits.shape[0]
         t_total += time.perf_counter() - t0
-    n = int(sum(len(ic.clip_starts(int(c) * 8)) for c in clips))
-    return {'videos': n_videos, 'clips': n, 'end_to_end_s': t_total, 'clips_per_s': n / t_total,
-            'note': 'per video: H2D of uint8 frames, fused transform, engine in batches of 32 (ragged last batch), '
-                    'counter; synthetic frame generation is outside the timed region (no decoder offline)'}
+    return {'videos': n_videos, 'clips': int(n), 'end_to_end_s': t_total, 'clips_per_s': n / t_total,
+            'note': 'per video: pin + H2D of the uint8 even frames (prefetched one video ahead on a side stream), fused '
+                    'transform, engine in batches of 32 (ragged last batch), one D2H, counter; synthetic frame '
+                    'generation is outside the timed region (no decoder offline)'}
 
 
 def config5(dtype, steps=10, warmup=3, batch=64):

@@ -32,11 +32,14 @@ Reference quirks reproduced by default (flags to change): frames are NOT divided
 """
 from __future__ import annotations
 
+import contextlib
 import json
 import os
 import os.path as osp
 from collections import deque
-from typing import Callable, Deque, Dict, Iterable, List, Optional, Sequence, Tuple, Union
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from typing import Callable, Deque, Dict, Iterable, Iterator, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -108,45 +111,82 @@ def _engine_device(model) -> Optional[torch.device]:
     return None
 
 
-def video_clip_logits(model, video_thwc_u8: torch.Tensor, transform: TestTransform,
-                      clip_range: Optional[Tuple[int, int]] = None, batch_clips: int = 32) -> torch.Tensor:
-    """Raw logits [n_clips_in_range, num_class] (CPU float32) for the clips ``clip_range`` (default all)
-    of one video.  Frames are transformed once each; clips are gathered from the transformed frames."""
+@dataclass
+class StagedVideo:
+    """The frames a clip range needs, on their way to (or already on) the engine's device."""
+    total: int                      # frames in the whole video
+    lo: int
+    hi: int                         # clip range [lo, hi)
+    f_lo: int                       # index (in even-frame units) of the first staged frame
+    hw: Tuple[int, int]
+    frames: torch.Tensor            # uint8 [n_even (+1 zero frame on the HIP path), H, W, 3]
+    on_device: bool
+    ready: Optional[object] = None  # torch.cuda.Event recorded after the H2D copy
+    _pinned: Optional[torch.Tensor] = None
+
+
+def stage_video(model, video_thwc_u8: torch.Tensor, clip_range: Optional[Tuple[int, int]] = None,
+                stream: Optional[object] = None) -> StagedVideo:
+    """Slice the even frames a clip range samples and, for a TsmEngine, copy them to its GPU through a
+    pinned buffer on ``stream`` (so the copy of video i+1 can run under the compute of video i)."""
     total = int(video_thwc_u8.shape[0])
     starts = clip_starts(total)
     lo, hi = clip_range if clip_range is not None else (0, len(starts))
+    hw = (int(video_thwc_u8.shape[1]), int(video_thwc_u8.shape[2]))
     if hi <= lo:
-        return torch.empty((0, getattr(model, 'num_class', 0)), dtype=torch.float32)
-    dev = _engine_device(model)
+        return StagedVideo(total, lo, lo, 0, hw, video_thwc_u8[:0], False)
     # only even source frames are ever sampled (starts are multiples of 8, stride 2)
     f_lo = starts[lo] // CLIP_STRIDE
     f_hi = min((starts[hi - 1] + CLIP_SPAN) // CLIP_STRIDE, (total + 1) // CLIP_STRIDE)
     even = video_thwc_u8[0::CLIP_STRIDE][f_lo:f_hi]
-    hip_transform = dev is not None and isinstance(transform, TestTransform) and hasattr(model, 'packed_layout')
+    dev = _engine_device(model)
+    if dev is None or not hasattr(model, 'packed_layout'):
+        return StagedVideo(total, lo, hi, f_lo, hw, even, False)
+    pinned = torch.empty((even.shape[0] + 1,) + tuple(even.shape[1:]), dtype=torch.uint8, pin_memory=True)
+    pinned[:-1].copy_(even)
+    pinned[-1].zero_()              # the zero frame the padded tail clip reads
+    ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+    with ctx:
+        frames = pinned.to(dev, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+    return StagedVideo(total, lo, hi, f_lo, hw, frames, True, ready, pinned)
+
+
+def staged_clip_logits(model, st: StagedVideo, transform: TestTransform, batch_clips: int = 32) -> torch.Tensor:
+    """Raw logits [hi - lo, num_class] (CPU float32) of a staged clip range.  Frames are transformed once
+    each; clips are gathered from the transformed frames."""
+    if st.hi <= st.lo:
+        return torch.empty((0, getattr(model, 'num_class', 0)), dtype=torch.float32)
+    starts = clip_starts(st.total)
+    dev = _engine_device(model)
+    hip_transform = st.on_device and isinstance(transform, TestTransform)
     if hip_transform:
         # HIP path: uint8 frames (+ one zero frame for the padded tail) -> fused resize/crop/normalise
-        # kernel -> NHWC4, which the engine consumes in place.
+        # kernel -> the engine's packed input format, consumed in place.
         from .engine import preprocess_frames
         packed_layout = model.packed_layout
-        even = torch.cat([even, torch.zeros((1,) + tuple(even.shape[1:]), dtype=even.dtype)]).to(dev, non_blocking=True)
-        frames = preprocess_frames(even, resize=transform.size, crop=transform.crop, scale_255=transform.scale_255,
-                                   layout=packed_layout)
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(st.ready)
+        st.frames.record_stream(cur)
+        frames = preprocess_frames(st.frames, resize=transform.size, crop=transform.crop,
+                                   scale_255=transform.scale_255, layout=packed_layout)
     else:
-        if dev is not None:
+        even = st.frames[:-1] if st.on_device else st.frames
+        if dev is not None and not even.is_cuda:
             even = even.to(dev, non_blocking=True)
         frames = transform(even.permute(0, 3, 1, 2).to(torch.float32))        # [n_even, 3, 224, 224]
-        zero = transform(torch.zeros((1, 3) + tuple(video_thwc_u8.shape[1:3]), dtype=torch.float32,
-                                     device=frames.device))                    # the zero-padded tail frame
-        frames = torch.cat([frames, zero], dim=0)
+        zero = transform(torch.zeros((1, 3) + st.hw, dtype=torch.float32, device=frames.device))
+        frames = torch.cat([frames, zero], dim=0)                              # + the zero-padded tail frame
     zi = frames.shape[0] - 1
-    idx = torch.tensor([[(s // CLIP_STRIDE + k - f_lo) if (s + CLIP_STRIDE * k) < total else zi
-                         for k in range(NUM_SEGMENTS)] for s in starts[lo:hi]], device=frames.device)
+    idx = torch.tensor([[(s // CLIP_STRIDE + k - st.f_lo) if (s + CLIP_STRIDE * k) < st.total else zi
+                         for k in range(NUM_SEGMENTS)] for s in starts[st.lo:st.hi]], device=frames.device)
     out = []
     for b in range(0, idx.shape[0], batch_clips):
-        clips = frames[idx[b:b + batch_clips]]                                # [b, 8, 3, 224, 224] / [b, 8, 224, 224, 4]
+        clips = frames[idx[b:b + batch_clips]]                                # [b, 8, 3, 224, 224] / packed
         if hip_transform:       # device logits are collected and copied to the host once per video
             out.append(model.forward_device(clips.contiguous(), layout=packed_layout))
-        elif dev is not None:
+        elif dev is not None and hasattr(model, 'forward_device'):
             out.append(model.forward_device(clips.contiguous()))
         else:
             name = model.get_inputs()[0].name
@@ -154,17 +194,60 @@ def video_clip_logits(model, video_thwc_u8: torch.Tensor, transform: TestTransfo
     return torch.cat(out, dim=0).to(torch.float32).cpu()
 
 
-def _gathered_video_logits(model, vid: torch.Tensor, transform: TestTransform, batch_clips: int) -> torch.Tensor:
-    """All clips of one video, sharded over the ranks of the default process group (if any)."""
-    rank, world = tdist.world_info()
-    n = len(clip_starts(int(vid.shape[0])))
-    if world == 1:
-        return video_clip_logits(model, vid, transform, None, batch_clips)
-    lo, hi = tdist.shard_range(n, world, rank)
-    local = video_clip_logits(model, vid, transform, (lo, hi), batch_clips)
+def video_clip_logits(model, video_thwc_u8: torch.Tensor, transform: TestTransform,
+                      clip_range: Optional[Tuple[int, int]] = None, batch_clips: int = 32) -> torch.Tensor:
+    """Raw logits [n_clips_in_range, num_class] (CPU float32) for the clips ``clip_range`` (default all)
+    of one video."""
+    return staged_clip_logits(model, stage_video(model, video_thwc_u8, clip_range), transform, batch_clips)
+
+
+def prefetch_staged(model, videos: Iterable[Tuple[object, torch.Tensor]],
+                    clip_range_of: Optional[Callable[[torch.Tensor], Optional[Tuple[int, int]]]] = None
+                    ) -> Iterator[Tuple[object, StagedVideo]]:
+    """Double buffering over a stream of ``(key, uint8 video)``: while the caller computes on video i, a
+    worker thread reads / slices / pins video i+1 and copies it to the GPU on a side stream."""
     dev = _engine_device(model)
+    side = torch.cuda.Stream(dev) if dev is not None and hasattr(model, 'packed_layout') else None
+
+    def work(item):
+        key, vid = item
+        vid = vid() if callable(vid) else vid          # lazy readers run on the worker thread too
+        rng = clip_range_of(vid) if clip_range_of is not None else None
+        return key, stage_video(model, vid, rng, side)
+
+    it = iter(videos)
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        try:
+            fut = pool.submit(work, next(it))
+        except StopIteration:
+            return
+        while fut is not None:
+            cur = fut.result()
+            try:
+                fut = pool.submit(work, next(it))
+            except StopIteration:
+                fut = None
+            yield cur
+
+
+def _rank_clip_range(total_frames: int) -> Optional[Tuple[int, int]]:
+    """This rank's contiguous block of the video's clips (None = all of them, single process)."""
+    rank, world = tdist.world_info()
+    if world == 1:
+        return None
+    return tdist.shard_range(len(clip_starts(total_frames)), world, rank)
+
+
+def _gather_video_logits(model, local: torch.Tensor, total_frames: int) -> torch.Tensor:
+    """All-gather the per-rank blocks of one video's clip logits (no-op in a single process)."""
+    rank, world = tdist.world_info()
+    if world == 1:
+        return local
+    n = len(clip_starts(total_frames))
+    lo, hi = tdist.shard_range(n, world, rank)
     num_class = getattr(model, 'num_class', local.shape[1] if local.numel() else 0)
     local = local.reshape(hi - lo, num_class)
+    dev = _engine_device(model)
     if dev is not None and torch.distributed.get_backend() == 'nccl':
         local = local.to(dev)
     return tdist.gather_clip_logits(local, n).cpu()
@@ -194,14 +277,16 @@ def inference_dataset(model, splits: List[str], out_dir: str, checkpoint: str, p
     reader = video_reader or read_video
     if rank == 0:
         print('==> transform:', transform)
-    for item in data.values():
-        vid = reader(item.video_path)
-        logits = _gathered_video_logits(model, vid, transform, batch_clips)
+    # Video i+1 is read, sliced, pinned and copied to the GPU by a worker thread while video i computes.
+    videos = ((item, (lambda p=item.video_path: reader(p))) for item in data.values())
+    for item, staged in prefetch_staged(model, videos, lambda v: _rank_clip_range(int(v.shape[0]))):
+        n_frames = staged.total
+        logits = _gather_video_logits(model, staged_clip_logits(model, staged, transform, batch_clips), n_frames)
         if rank != 0:
             continue
         res_dict = dict(video_name=item.video_name, model='video_model', input_shape=[1, 8, 3, 224, 224],
-                        checkpoint=checkpoint, total_frames=len(vid), ground_truth=item.reps, action=item.class_)
-        res_dict['scores'] = scores_dict(logits, len(vid))
+                        checkpoint=checkpoint, total_frames=n_frames, ground_truth=item.reps, action=item.class_)
+        res_dict['scores'] = scores_dict(logits, n_frames)
         out_path = os.path.join(out_dir, f'{item.video_name}.score.json')
         with open(out_path, 'w') as f:
             json.dump(res_dict, f)
