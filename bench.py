@@ -213,7 +213,7 @@ def main():
             groups.setdefault(tiles[r['name']], []).extend(d[r['name']] for d in per_launch)
         dom_tile, dom_ms = max(groups.items(), key=lambda kv: sum(kv[1]))
         prec_id = {'f32': 0, 'bf16x3': 1, 'bf16': 2}[args.dtype]
-        dom_kernel = 'conv_igemm<%s, 2, 2, 3, false, false, %d>' % (dom_tile.replace('x', ', '), prec_id)
+        dom_kernel = 'conv_igemm<%s, 2, 2, 3, false, false, %d, false>' % (dom_tile.replace('x', ', '), prec_id)
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         peak_name = ('dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); the kernel executes 3 MFMA FLOPs per algorithmic FLOP'
                      if args.dtype == 'bf16x3' else 'dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)' if args.dtype == 'bf16'

@@ -26,24 +26,25 @@ def last_forward(per, names):
     return [d for d in ids if packs[-2] <= d < packs[-1]]
 
 
-def main(fetch_csv, write_csv, dominant='conv_igemm_f32<128, 128, 2, 2, 3, false, false>'):
+def main(fetch_csv, write_csv, dominant='conv_igemm<64, 64, 2, 2, 3, false, false, 0, false>'):
     f, fn = load(fetch_csv, 'FETCH_SIZE')
     w, wn = load(write_csv, 'WRITE_SIZE')
+    # The two passes are separate processes and the engine's tile autotuner may pick a different shape for
+    # a few layers in each, so the passes are summarised independently (per kernel name), not zipped.
     fi, wi = last_forward(f, fn), last_forward(w, wn)
-    assert [fn[d] for d in fi] == [wn[d] for d in wi]
-    tot_r = tot_w = 0.0
-    dom = []
-    for a, b in zip(fi, wi):
-        rd, wr = 2.0 * f[a] * 1024, w[b] * 1024
-        tot_r += rd
-        tot_w += wr
-        if dominant in fn[a]:
-            dom.append(rd + wr)
+    tot_r = sum(2.0 * f[d] * 1024 for d in fi)
+    tot_w = sum(w[d] * 1024 for d in wi)
+    dom_r = [2.0 * f[d] * 1024 for d in fi if dominant in fn[d]]
+    dom_w = [w[d] * 1024 for d in wi if dominant in wn[d]]
     print(f'forward: read {tot_r / 1e9:.3f} GB (FETCH_SIZE x2 x1024), write {tot_w / 1e9:.3f} GB, total {(tot_r + tot_w) / 1e9:.3f} GB')
-    if dom:
-        print(f'{dominant}: {len(dom)} launches, avg {sum(dom) / len(dom) / 1e6:.1f} MB per launch')
-    return (tot_r + tot_w), (sum(dom) / len(dom) if dom else None)
+    per_launch = None
+    if dom_r and dom_w:
+        per_launch = sum(dom_r) / len(dom_r) + sum(dom_w) / len(dom_w)
+        print(f'{dominant}: {len(dom_r)} / {len(dom_w)} launches in the read / write pass, '
+              f'avg read {sum(dom_r) / len(dom_r) / 1e6:.1f} MB + write {sum(dom_w) / len(dom_w) / 1e6:.1f} MB '
+              f'= {per_launch / 1e6:.1f} MB per launch')
+    return (tot_r + tot_w), per_launch
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])

@@ -19,18 +19,20 @@ def main(path, frames=256):
     convs = [r for r in fw if 'conv_' in r['Kernel_Name']]
     byname = {r['name']: r for r in layer_table()}
     order = ['conv1']
+    fused = len(convs) == 49          # conv3 + downsample of each stage's first block run as one launch
     for li, nb in enumerate((3, 4, 6, 3), 1):
         for b in range(nb):
             p = f'layer{li}.{b}'
-            if b == 0:
+            if b == 0 and not fused:
                 order.append(p + '.downsample')
-            order += [p + '.conv1', p + '.conv2', p + '.conv3']
+            order += [p + '.conv1', p + '.conv2', p + '.conv3' + ('+downsample' if (b == 0 and fused) else '')]
     if len(order) != len(convs):
         print('launch count', len(convs), 'differs from layer count', len(order))
     tot = totf = 0.0
     for nm, r in zip(order, convs):
         dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-        fl = 2 * byname[nm]['macs'] * frames
+        fl = 2 * frames * (byname[nm]['macs'] if '+' not in nm else
+                           byname[nm.split('+')[0]]['macs'] + byname[nm.split('.conv3')[0] + '.downsample']['macs'])
         tot += dur
         totf += fl
         kn = r['Kernel_Name'].split('<')[1].split('>')[0] if '<' in r['Kernel_Name'] else r['Kernel_Name'][:30]
