@@ -134,3 +134,26 @@ def test_autotuned_tiles_are_bitwise_invariant(hip_lib, sd0, monkeypatch):
         assert np.array_equal(outs[name], again)
         eng.close()
     assert np.array_equal(outs['tuned'], outs['heuristic'])
+
+
+def test_create_model_from_checkpoint_and_onnx(hip_lib, sd0, tmp_path):
+    """The three weight sources give the same logits: state dict, torch checkpoint with 'module.' keys
+    (create_model's remap, tsm.py:451-473) and a BN-folded .onnx export (onnx_import)."""
+    from tests._onnx_writer import write_model
+    from tests.test_onnx_import import _folded_export
+    from workoutdetector_amd.engine import TsmEngine, create_model
+    x = make_input(9, 1, 8, 64, 64)
+    ref = TsmEngine(height=64, width=64, max_clips=1, state_dict=sd0)
+    want = ref.run(None, {'input': x})[0]
+    ref.close()
+    keys = list(sd0)
+    ck = {'state_dict': {('module.' + k).replace('module.fc.', 'module.new_fc.'): sd0[k] for k in keys}}
+    torch.save(ck, tmp_path / 'tsm.pth')
+    m = create_model(num_class=12, checkpoint=str(tmp_path / 'tsm.pth'), device='cuda:0', height=64, width=64, max_clips=1)
+    assert np.array_equal(m.run(None, {'input': x})[0], want)
+    m.close()
+    nodes, inits = _folded_export({k: v.numpy() for k, v in sd0.items()})
+    write_model(str(tmp_path / 'tsm.onnx'), nodes, inits)
+    m = create_model(num_class=12, checkpoint=str(tmp_path / 'tsm.onnx'), device='cuda:0', height=64, width=64, max_clips=1)
+    assert_close(m.run(None, {'input': x})[0], want, rtol=1e-5, atol_scale=1e-6, what='onnx-imported weights')
+    m.close()

@@ -235,7 +235,9 @@ def create_model(num_class: int = 2, num_segments: int = 8, base_model: str = 'r
     """Counterpart of the reference factory (tsm.py:422-476) returning a ready TsmEngine.
 
     ``checkpoint`` is a ``torch.save``d dict with a ``state_dict`` entry; its keys are remapped like
-    the reference does (strip the first dotted component, last two entries are the classifier).
+    the reference does (strip the first dotted component, last two entries are the classifier).  A path
+    ending in ``.onnx`` (the reference's exported model, scripts/export_model.py:35-47) is read by
+    ``onnx_import.load_onnx_state_dict``.
     Without a checkpoint the reference starts from torchvision's ImageNet weights, which cannot be
     fetched offline: the engine then gets the seeded synthetic weights of ``weights.make_state_dict``.
     """
@@ -251,7 +253,10 @@ def create_model(num_class: int = 2, num_segments: int = 8, base_model: str = 'r
         if s == 'cpu':
             raise RuntimeError('TsmEngine has no CPU path; pass a CUDA/HIP device')
         dev = int(s.split(':')[1]) if ':' in s else 0
-    if checkpoint is not None:
+    if checkpoint is not None and str(checkpoint).endswith('.onnx'):
+        from .onnx_import import load_onnx_state_dict        # the reference's deployed artefact
+        sd = load_onnx_state_dict(checkpoint, num_class)
+    elif checkpoint is not None:
         import torch
         ckpt = torch.load(checkpoint, map_location='cpu')
         sd = remap_checkpoint_keys(ckpt['state_dict'], num_class)
