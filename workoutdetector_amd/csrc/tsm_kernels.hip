@@ -83,7 +83,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 //                32-byte group [hi x8 | lo x8] (same 4 bytes per element, same byte offsets as fp32, so the
 //                loader is shared).  a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32
 //                accumulation: relative error ~2^-17 per product, three MFMAs at 16x the fp32-MFMA rate.
-template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false>
+template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false, bool RKT = true>
 __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   static_assert(!DUAL || (KS == 1 && !SHIFT && !RES), "K-concatenated second source: plain 1x1 convs only");
@@ -95,11 +95,17 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int APASS = BM / 32, BPASS = BN / 32;
+  // RK ("register-resident K-step", fp32 64x64 tiles): ONE LDS buffer; after the barrier that makes a
+  // tile visible every wave pulls all four k-groups of fragments into registers, a second barrier frees the
+  // buffer, and the 16 MFMAs of the step then run from registers while the next tile is written into LDS.
+  // Half the LDS per workgroup -> more workgroups per CU, and no LDS wait inside the MFMA sequence.
+  constexpr bool RK = RKT && PREC == kPrecF32 && BM == 64 && BN == 64;
+  constexpr int NBUF = RK ? 1 : 2;
   constexpr int CLD = BN + 4;  // epilogue staging row stride (floats)
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
-  static_assert(BM * CLD <= 2 * (BM + BN) * kLds, "epilogue staging must fit the operand buffers");
+  static_assert(BM * CLD <= NBUF * (BM + BN) * kLds, "epilogue staging must fit the operand buffers");
 
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * kLds];
+  __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * kLds];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -465,6 +471,39 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
       frag_load_bf(cur ^ 1, 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+  } else if constexpr (RK) {
+    f32x4 ra_[4], rb_[4];  // all four k-groups of this wave's A / B fragments (TM = TN = 1)
+    for (int kt = 0; kt < nk; ++kt) {
+      const KStep k2 = kstep(kt + 2, nk);
+      {
+        const float *As = smem + (wm * WTM + l31) * kLds + half * 4;
+        const float *Bs = smem + BM * kLds + (wn * WTN + l31) * kLds + half * 4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          ra_[kk] = *reinterpret_cast<const f32x4 *>(As + kk * 8);
+          rb_[kk] = *reinterpret_cast<const f32x4 *>(Bs + kk * 8);
+        }
+      }
+      __syncthreads();  // every wave holds its fragments: the buffer may be overwritten
+      int cnt = 0;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_[kk][s4], rb_[kk][s4], acc[0][0], 0, 0, 0);
+          ++cnt;
+          // 2*NITEMS loader items over the first 12 MFMAs: the ds_writes of tile kt+1, then the loads of kt+2
+          const int done = cnt < 12 ? (cnt * 2 * NITEMS) / 12 : 2 * NITEMS;
+          const int before = cnt - 1 < 12 ? ((cnt - 1) * 2 * NITEMS) / 12 : 2 * NITEMS;
+#pragma unroll
+          for (int it = before; it < done; ++it) {
+            if (it < NITEMS) lstore_item(0, it);
+            else gload_item(k2, kt + 2, it - NITEMS);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      __syncthreads();  // tile kt+1 is complete in LDS
+    }
   } else if constexpr (!X3) {
     frag_load(0, 0, 0);
     frag_load(0, 1, 1);
@@ -611,8 +650,13 @@ static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
     hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16x3>), grid, dim3(256), 0, s, p);
   else if (p.prec == kPrecBf16)
     hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16>), grid, dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32>), grid, dim3(256), 0, s, p);
+  else {
+    static const bool rk_off = getenv("TSM_CONV_RK") && atoi(getenv("TSM_CONV_RK")) == 0;  // A/B hook
+    if (BM == 64 && BN == 64 && rk_off)
+      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32, false, false>), grid, dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32>), grid, dim3(256), 0, s, p);
+  }
   return hipGetLastError();
 }
 
