@@ -157,3 +157,23 @@ def test_create_model_from_checkpoint_and_onnx(hip_lib, sd0, tmp_path):
     m = create_model(num_class=12, checkpoint=str(tmp_path / 'tsm.onnx'), device='cuda:0', height=64, width=64, max_clips=1)
     assert_close(m.run(None, {'input': x})[0], want, rtol=1e-5, atol_scale=1e-6, what='onnx-imported weights')
     m.close()
+
+
+def test_fp32_pipeline_variants_are_bit_identical(hip_lib, sd0, monkeypatch):
+    """TSM_CONV_RK selects the fp32 64x64 pipeline (two LDS buffers / register-resident K-step / the same fed by
+    LDS-DMA with an XOR-swizzled image).  Same k order in all three, so logits and taps must match bit for bit."""
+    from workoutdetector_amd.engine import TsmEngine
+    x = make_input(31, 2, 8, 96, 96)
+    monkeypatch.setenv('TSM_AUTOTUNE', '0')
+    monkeypatch.setenv('TSM_CONV_TILE', '64x64')
+    outs, taps = {}, {}
+    for rk in ('0', '1', '2'):
+        monkeypatch.setenv('TSM_CONV_RK', rk)
+        eng = TsmEngine(height=96, width=96, max_clips=2, state_dict=sd0)
+        outs[rk] = eng.run(None, {'input': x})[0]
+        taps[rk] = eng.forward_tap(x, 'layer2.0')
+        eng.close()
+    assert np.array_equal(outs['0'], outs['1']) and np.array_equal(outs['0'], outs['2'])
+    assert np.array_equal(taps['0'], taps['1']) and np.array_equal(taps['0'], taps['2'])
+    want = tsm_oracle.tsm_forward(sd0, torch.from_numpy(x)).numpy()
+    assert_close(outs['2'], want, rtol=1e-3, atol_scale=1e-4, what='dma variant vs oracle')

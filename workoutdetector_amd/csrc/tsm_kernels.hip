@@ -83,7 +83,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 //                32-byte group [hi x8 | lo x8] (same 4 bytes per element, same byte offsets as fp32, so the
 //                loader is shared).  a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32
 //                accumulation: relative error ~2^-17 per product, three MFMAs at 16x the fp32-MFMA rate.
-template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false, bool RKT = true>
+template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false, int RKT = 1>
 __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   static_assert(!DUAL || (KS == 1 && !SHIFT && !RES), "K-concatenated second source: plain 1x1 convs only");
@@ -99,13 +99,19 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   // tile visible every wave pulls all four k-groups of fragments into registers, a second barrier frees the
   // buffer, and the 16 MFMAs of the step then run from registers while the next tile is written into LDS.
   // Half the LDS per workgroup -> more workgroups per CU, and no LDS wait inside the MFMA sequence.
-  constexpr bool RK = RKT && PREC == kPrecF32 && BM == 64 && BN == 64;
+  constexpr bool RK = RKT != 0 && PREC == kPrecF32 && BM == 64 && BN == 64;
+  // RKT == 2: the single buffer is filled by LDS-DMA (buffer_load ... lds): no staging registers, no
+  // ds_write.  The DMA image is lane-linear (1 KiB per wave-instruction = 8 rows x 128 B), so rows are
+  // NOT padded; bank conflicts are removed by an XOR swizzle of the 16-byte chunk index with
+  // f(row) = (row >> 1) & 7, applied on the per-lane SOURCE offset and on the fragment reads.
+  constexpr bool DMA = RK && RKT == 2;
+  constexpr int LDR = DMA ? 32 : kLds;  // LDS row stride in floats
   constexpr int NBUF = RK ? 1 : 2;
   constexpr int CLD = BN + 4;  // epilogue staging row stride (floats)
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
-  static_assert(BM * CLD <= NBUF * (BM + BN) * kLds, "epilogue staging must fit the operand buffers");
+  constexpr int SMEM_FLOATS = NBUF * (BM + BN) * LDR > BM * CLD ? NBUF * (BM + BN) * LDR : BM * CLD;
 
-  __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * kLds];
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -142,7 +148,9 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
       (int)(a2_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : a2_bytes), 0x00020000);
 
   // ---- per-thread loader state: 8 threads per 32-float row, 32 rows per pass -------------------
-  const int chunk = tid & 7, lrow = tid >> 3;
+  // DMA: this lane fills LDS slot (row, tid & 7), which holds global chunk (tid & 7) ^ f(row)
+  const int lrow = tid >> 3;
+  const int chunk = DMA ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);
   const int frame_bytes = (int)(frame_elems * EB);
   unsigned a_off[APASS];                       // byte offset of (row, tap 0, this thread's chunk)
   unsigned a_offp[SHIFT ? APASS : 1], a_offm[SHIFT ? APASS : 1];
@@ -266,6 +274,48 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
       *reinterpret_cast<f32x4 *>(As + (lrow + 32 * item) * kLds + chunk * 4) = ra[item];
     else
       *reinterpret_cast<f32x4 *>(As + BM * kLds + (lrow + 32 * (item - APASS)) * kLds + chunk * 4) = rb[item - APASS];
+  };
+
+  // LDS-DMA item: the same offsets as gload_item, but the 16 bytes of every lane land directly in LDS
+  // (wave-uniform base + lane * 16); out-of-range lanes are written as zeros by the hardware.
+  auto dma_item = [&](const KStep &k, int kt, int item) {
+    unsigned voff, soff = 0;
+    __amdgpu_buffer_rsrc_t rs = rsrcA;
+    int row0;
+    if (item < APASS) {
+      const int pp = item;
+      row0 = 32 * pp;
+      if (KS == 1) {
+        unsigned off = a_off[pp];
+        if (SHIFT) off = (a_offp[pp] & k.mp) | (a_offm[pp] & k.mm) | (a_off[pp] & k.m0);
+        if (DUAL) {
+          const bool second = kt >= nk1;
+          rs = second ? rsrcA2 : rsrcA;
+          voff = (second ? a_off2[pp] : off) | k.dead;
+          soff = second ? k.kbytes - (unsigned)nk1 * 128u : k.kbytes;
+        } else {
+          voff = off | k.dead;
+          soff = k.kbytes;
+        }
+      } else if (KS == 3) {
+        voff = (((a_mask[pp] >> k.tap) & 1u) ? a_off[pp] + (unsigned)k.tap_off : kInvalid) | k.dead;
+      } else {
+        const int tap = kt * 8 + chunk;
+        const int ky = tap / 7, kx = tap - ky * 7;
+        const int iy = a_iy[pp] + ky, ix = a_ix[pp] + kx;
+        const bool ok = tap < 49 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        voff = (ok ? a_off[pp] + (unsigned)((iy * p.Wi + ix) * 16) : kInvalid) | k.dead;
+      }
+    } else {
+      const int pp = item - APASS;
+      row0 = BM + 32 * pp;
+      rs = rsrcB;
+      voff = b_off[pp] | k.dead;
+      soff = k.kbytes;
+    }
+    float *dst = smem + (row0 + 8 * wave) * LDR;  // wave-uniform: this wave's 8 rows of the pass
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, (int)voff,
+                                             (int)soff, 0, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -434,7 +484,11 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   // One barrier per step suffices: tile kt+1 is complete in LDS before it, and nobody overwrites
   // buf[kt&1] before the next barrier.  The body is straight-line.
   const int nk = p.Kp / KC;
-  {
+  if constexpr (DMA) {
+    const KStep k0 = kstep(0, nk);
+#pragma unroll
+    for (int it = 0; it < NITEMS; ++it) dma_item(k0, 0, it);
+  } else {
     const KStep k0 = kstep(0, nk);
 #pragma unroll
     for (int it = 0; it < NITEMS; ++it) gload_item(k0, 0, it);
@@ -444,7 +498,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
 #pragma unroll
     for (int it = 0; it < NITEMS; ++it) gload_item(k1, 1, it);
   }
-  __syncthreads();
+  __syncthreads();  // (waits for outstanding LDS-DMA too: it is a pending LDS write on the VM counter)
   if constexpr (BF) {
     // plain bf16: four k16-groups of TM*TN MFMAs per K-step.  Groups 0-1 carry the ds_writes of tile kt+1
     // and the buffer loads of tile kt+2; groups 2-3 run after the barrier and cover the next fragments.
@@ -470,6 +524,36 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
       __builtin_amdgcn_sched_barrier(0);
       frag_load_bf(cur ^ 1, 1);
       __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (DMA) {
+    f32x4 ra_[4], rb_[4];  // all four k-groups of this wave's A / B fragments (TM = TN = 1)
+    const int fsw = (l31 >> 1) & 7;  // f(row) of this lane's fragment row (tile offsets are multiples of 32)
+    for (int kt = 0; kt < nk; ++kt) {
+      const KStep k1 = kstep(kt + 1, nk);
+      {
+        const float *As = smem + (wm * WTM + l31) * LDR;
+        const float *Bs = smem + (BM + wn * WTN + l31) * LDR;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int slot = ((kk * 2 + half) ^ fsw) * 4;
+          ra_[kk] = *reinterpret_cast<const f32x4 *>(As + slot);
+          rb_[kk] = *reinterpret_cast<const f32x4 *>(Bs + slot);
+        }
+      }
+      __syncthreads();  // every wave holds its fragments: the buffer may be overwritten
+      int cnt = 0;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_[kk][s4], rb_[kk][s4], acc[0][0], 0, 0, 0);
+          ++cnt;
+          if (cnt <= NITEMS) {  // one DMA item behind each of the first MFMAs: tile kt+1 streams in under the rest
+            dma_item(k1, kt + 1, cnt - 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      __syncthreads();  // vmcnt(0) + barrier: tile kt+1 is complete in LDS
     }
   } else if constexpr (RK) {
     f32x4 ra_[4], rb_[4];  // all four k-groups of this wave's A / B fragments (TM = TN = 1)
@@ -651,9 +735,15 @@ static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
   else if (p.prec == kPrecBf16)
     hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16>), grid, dim3(256), 0, s, p);
   else {
-    static const bool rk_off = getenv("TSM_CONV_RK") && atoi(getenv("TSM_CONV_RK")) == 0;  // A/B hook
-    if (BM == 64 && BN == 64 && rk_off)
-      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32, false, false>), grid, dim3(256), 0, s, p);
+    // fp32 64x64 pipeline variant: 0 = two LDS buffers, 1 = register-resident K-step (default), 2 = the same
+    // fed by LDS-DMA.  All three accumulate in the same order (bit-identical results); measured within
+    // 1.5 % of each other, 1 marginally ahead.  Read per launch so tests can switch it.
+    const char *rk_env = getenv("TSM_CONV_RK");
+    const int rk = rk_env ? atoi(rk_env) : 1;
+    if (BM == 64 && BN == 64 && rk == 0)
+      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32, false, 0>), grid, dim3(256), 0, s, p);
+    else if (BM == 64 && BN == 64 && rk == 2)
+      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32, false, 2>), grid, dim3(256), 0, s, p);
     else
       hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32>), grid, dim3(256), 0, s, p);
   }
