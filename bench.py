@@ -213,7 +213,9 @@ def main():
             groups.setdefault(tiles[r['name']], []).extend(d[r['name']] for d in per_launch)
         dom_tile, dom_ms = max(groups.items(), key=lambda kv: sum(kv[1]))
         prec_id = {'f32': 0, 'bf16x3': 1, 'bf16': 2}[args.dtype]
-        dom_kernel = 'conv_igemm<%s, 2, 2, 3, false, false, %d, false>' % (dom_tile.replace('x', ', '), prec_id)
+        main_tile = dom_tile.split('+')[0]
+        waves = '1, 1' if main_tile == '32x32' else '2, 2'
+        dom_kernel = 'conv_igemm<%s, %s, 3, false, false, %d, false>' % (main_tile.replace('x', ', '), waves, prec_id)
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         peak_name = ('dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); the kernel executes 3 MFMA FLOPs per algorithmic FLOP'
                      if args.dtype == 'bf16x3' else 'dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)' if args.dtype == 'bf16'
@@ -234,8 +236,10 @@ def main():
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'traffic': measured_traffic(B, T, H, W, dom_kernel),
                          'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/traffic.json)',
-                         'kernel': dom_kernel + ' (3x3 convs of layer2-4, %d of 13 launches per forward)'
-                                   % (len(dom_ms) // len(per_launch)),
+                         'kernel': dom_kernel + ' (3x3 convs of layer2-4, %d of 13 launches per forward%s)'
+                                   % (len(dom_ms) // len(per_launch),
+                                      '; tail rows on single-wave 32x32 tiles of the same kernel, overlapped on a '
+                                      'second stream and inside the timed launch' if '+' in dom_tile else ''),
                          'gflop_per_launch': round(dom_gflop, 3), 'avg_launch_ms': round(dom_avg_ms, 4),
                          'launches_timed': len(dom_ms),
                          'peak_name': peak_name,

@@ -140,8 +140,9 @@ int tsm_set_layer_timing(tsm_engine *e, int32_t n_forwards, int32_t only_conv3x3
 int tsm_layer_times(tsm_engine *e, int32_t forward_index, float *ms_out, int32_t cap, int32_t *n_out);
 
 /* Conv tile shape the engine's autotuner chose for each conv launch of an `n_clips` forward, in launch
- * order (stem, then per block [downsample,] conv1, conv2, conv3): 1 = 128x128, 2 = 128x64, 3 = 64x64,
- * 0 = not tuned (heuristic).  The first tsm_forward with a new n_clips times every valid shape per
+ * order (stem, then per block [downsample,] conv1, conv2, conv3), as `main + 16 * tail`: 1 = 128x128,
+ * 2 = 128x64, 3 = 64x64, 4 = 32x32 (one wave), 0 = not tuned (heuristic); tail != 0 means the rows that do
+ * not fill whole rounds of the chip with `main` tiles run on `tail` tiles on a second stream.  The first tsm_forward with a new n_clips times every valid shape per
  * layer once (results are bit-identical across shapes); TSM_AUTOTUNE=0 in the environment disables it. */
 int tsm_conv_tiles(tsm_engine *e, int32_t n_clips, int32_t *tiles_out, int32_t cap, int32_t *n_out);
 

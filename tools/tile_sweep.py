@@ -27,12 +27,15 @@ print(json.dumps({k: sorted(v)[len(v)//2] for k, v in acc.items()}))
 ''' % ROOT
 
 res = {}
-for tile in ['default', '128x128', '128x64', '64x64']:
+for tile in ['default', '64x64', '32x32', 'code67']:
     env = dict(os.environ)
     env['TSM_AUTOTUNE'] = '1' if tile == 'default' else '0'
     if len(sys.argv) > 1:
         env['TSM_SWEEP_DTYPE'] = sys.argv[1]
-    if tile != 'default':
+    if tile.startswith('code'):
+        env['TSM_CONV_CODE'] = tile[4:]
+        env['TSM_AUTOTUNE'] = '1'
+    elif tile != 'default':
         env['TSM_CONV_TILE'] = tile
     out = subprocess.run([sys.executable, '-c', CHILD], env=env, capture_output=True, text=True)
     if out.returncode != 0:

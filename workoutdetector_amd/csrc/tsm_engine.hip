@@ -134,6 +134,11 @@ struct tsm_engine {
   std::map<int, std::vector<int>> tile_cache;
   bool autotune = true;
   bool fuse_down = true;  // TSM_FUSE_DOWNSAMPLE=0 runs the downsample branch as its own launch
+  // tail launches: fine (32x32, one wave) tiles for the rows the coarse tiles cannot spread evenly over the
+  // CUs, issued on a second stream so that they overlap the coarse launch
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int n_cu = 256;
   int timing_left = 0;
   bool timing_only3x3 = false;
   std::vector<std::vector<hipEvent_t>> timing;
@@ -316,21 +321,52 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     }
     tiles = &it->second;
   }
+  // A tile code is `main + 16 * tail`: tail == 0 -> one launch with tile `main`; otherwise the first rows
+  // go to `main` tiles (a whole number of full-occupancy rounds) and the rest to `tail` tiles on stream2.
+  // Every output element accumulates its K in the same order whatever the tiling, so codes are bit-neutral.
+  auto launch_code = [&](tsm::ConvParams p, int ks, int code) -> hipError_t {
+    const int main_tile = code & 15, tail_tile = code >> 4;
+    p.tile = main_tile;
+    if (tail_tile == 0) return tsm::launch_conv(p, ks, s);
+    int bm, bn;
+    tsm::conv_tile_dims(main_tile, &bm, &bn);
+    const int ntn = p.Cout / bn, ntm = (p.M + bm - 1) / bm;
+    const long slots = (long)e->n_cu * (bm == 64 ? 5 : 2);  // resident workgroups of the coarse kernel
+    const long full = ((long)ntm * ntn / slots) * slots;      // tiles in whole rounds
+    const int mt = (int)(full / ntn);                         // m-tiles fully covered by them
+    if (mt <= 0 || mt >= ntm) return tsm::launch_conv(p, ks, s);
+    hipError_t st = hipEventRecord(e->ev_fork, s);
+    if (st == hipSuccess) st = hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
+    tsm::ConvParams pm = p, pt = p;
+    pm.m_begin = 0; pm.m_end = mt * bm;
+    pt.m_begin = mt * bm; pt.m_end = p.M; pt.tile = tail_tile;
+    if (st == hipSuccess) st = tsm::launch_conv(pm, ks, s);
+    if (st == hipSuccess) st = tsm::launch_conv(pt, ks, e->stream2);
+    if (st == hipSuccess) st = hipEventRecord(e->ev_join, e->stream2);
+    if (st == hipSuccess) st = hipStreamWaitEvent(s, e->ev_join, 0);
+    return st;
+  };
   auto conv = [&](int idx, tsm::ConvParams p, int ks, bool is3x3) -> int {
-    if (tiles && !tuning) p.tile = (*tiles)[idx];
     if (!tuning) {
-      TSM_LAUNCH_K(e, s, is3x3, tsm::launch_conv(p, ks, s));
+      int code = tiles ? (*tiles)[idx] : 0;
+      static const char *force_code = getenv("TSM_CONV_CODE");  // tuning hook: force one tile code everywhere
+      if (force_code && tsm::conv_tile_valid(p, atoi(force_code) & 15)) code = atoi(force_code);
+      TSM_LAUNCH_K(e, s, is3x3, launch_code(p, ks, code));
       return TSM_OK;
     }
     float best_ms = 0.f;
     int best = 0;
-    for (int t = 1; t < tsm::kNumTiles; ++t) {
-      p.tile = t;
-      if (!tsm::conv_tile_valid(p, t)) continue;
+    std::vector<int> cands;
+    for (int t = 1; t < tsm::kNumTiles; ++t)
+      if (tsm::conv_tile_valid(p, t)) cands.push_back(t);
+    // The coarse + tail code (64x64 rounds, 32x32 single-wave tiles for the leftover rows on stream2) is NOT
+    // a candidate: measured slower than plain 64x64 on every layer at batch 32 (layer4 conv2 522 vs 489 us),
+    // see DESIGN.md; TSM_CONV_CODE=67 still forces it for experiments.
+    for (int t : cands) {
       float ms[3];
       for (int rep = 0; rep < 3; ++rep) {
         TSM_HIP(e, hipEventRecord(e->ev0, s));
-        TSM_HIP(e, tsm::launch_conv(p, ks, s));
+        TSM_HIP(e, launch_code(p, ks, t));
         TSM_HIP(e, hipEventRecord(e->ev1, s));
         TSM_HIP(e, hipEventSynchronize(e->ev1));
         TSM_HIP(e, hipEventElapsedTime(&ms[rep], e->ev0, e->ev1));
@@ -473,6 +509,10 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   build_topology(e);
   st = hipSetDevice(cfg->device_id);
   if (st == hipSuccess) st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (st == hipSuccess) st = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking);
+  if (st == hipSuccess) st = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+  if (st == hipSuccess) st = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
+  if (st == hipSuccess) st = hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
   if (st == hipSuccess) st = hipEventCreate(&e->ev0);
   if (st == hipSuccess) st = hipEventCreate(&e->ev1);
   if (st != hipSuccess) {
@@ -493,6 +533,9 @@ void tsm_destroy(tsm_engine *e) {
     for (hipEvent_t ev : v)
       if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->stream2) (void)hipStreamDestroy(e->stream2);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->stream) (void)hipStreamDestroy(e->stream);

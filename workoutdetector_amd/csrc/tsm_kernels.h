@@ -30,11 +30,15 @@ struct ConvParams {
   const float *x2;
   int C2, Hi2, Wi2, stride2;
   int K1;    // channels of the first source (its K extent); Kp = K1 + C2
+  // Row range of this launch, [m_begin, m_end) of the M output pixels (m_end <= 0: all of them).  Lets a
+  // layer be covered by two launches with different tile shapes (coarse tiles + fine tiles for the tail).
+  int m_begin, m_end;
 };
 
 enum ConvPrec { kPrecF32 = 0, kPrecBf16x3 = 1, kPrecBf16 = 2 };
 
-enum ConvTile { kTileAuto = 0, kTile128x128 = 1, kTile128x64 = 2, kTile64x64 = 3, kNumTiles = 4 };
+enum ConvTile { kTileAuto = 0, kTile128x128 = 1, kTile128x64 = 2, kTile64x64 = 3, kTile32x32 = 4, kNumTiles = 5 };
+void conv_tile_dims(int tile, int *bm, int *bn);
 // Is `tile` usable for this problem (Cout divisibility)?
 bool conv_tile_valid(const ConvParams &p, int tile);
 

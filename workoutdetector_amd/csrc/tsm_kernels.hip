@@ -84,8 +84,10 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 //                loader is shared).  a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32
 //                accumulation: relative error ~2^-17 per product, three MFMAs at 16x the fp32-MFMA rate.
 template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false, int RKT = 1>
-__global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
-  static_assert(WGM * WGN == 4, "4 waves per workgroup");
+__global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p) {
+  static_assert(WGM * WGN == 4 || WGM * WGN == 1, "4 waves per workgroup, or 1 (32x32 tail / small-M tiles)");
+  constexpr int NT = 64 * WGM * WGN;   // threads per workgroup
+  constexpr int LRP = NT / 8;          // loader rows per pass (8 threads x 16 bytes per 128-byte row)
   static_assert(!DUAL || (KS == 1 && !SHIFT && !RES), "K-concatenated second source: plain 1x1 convs only");
   constexpr bool X3 = PREC == kPrecBf16x3;
   constexpr bool BF = PREC == kPrecBf16;   // plain bf16 storage, one bf16 MFMA per product (config 5)
@@ -94,17 +96,17 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   static_assert(!SHIFT || KS == 1, "the temporal shift is fused into 1x1 convs only");
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int APASS = BM / 32, BPASS = BN / 32;
+  constexpr int APASS = BM / LRP, BPASS = BN / LRP;
   // RK ("register-resident K-step", fp32 64x64 tiles): ONE LDS buffer; after the barrier that makes a
   // tile visible every wave pulls all four k-groups of fragments into registers, a second barrier frees the
   // buffer, and the 16 MFMAs of the step then run from registers while the next tile is written into LDS.
   // Half the LDS per workgroup -> more workgroups per CU, and no LDS wait inside the MFMA sequence.
-  constexpr bool RK = RKT != 0 && PREC == kPrecF32 && BM == 64 && BN == 64;
+  constexpr bool RK = RKT != 0 && PREC == kPrecF32 && ((BM == 64 && BN == 64) || (BM == 32 && BN == 32));
   // RKT == 2: the single buffer is filled by LDS-DMA (buffer_load ... lds): no staging registers, no
   // ds_write.  The DMA image is lane-linear (1 KiB per wave-instruction = 8 rows x 128 B), so rows are
   // NOT padded; bank conflicts are removed by an XOR swizzle of the 16-byte chunk index with
   // f(row) = (row >> 1) & 7, applied on the per-lane SOURCE offset and on the fragment reads.
-  constexpr bool DMA = RK && RKT == 2;
+  constexpr bool DMA = RK && RKT == 2 && NT == 256;
   constexpr int LDR = DMA ? 32 : kLds;  // LDS row stride in floats
   constexpr int NBUF = RK ? 1 : 2;
   constexpr int CLD = BN + 4;  // epilogue staging row stride (floats)
@@ -125,7 +127,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = p.m_begin + tm * BM, n0 = tn * BN;   // m_begin: this launch covers rows [m_begin, m_end)
 
   // ---- descriptors, rebased to this workgroup's first input frame / first weight row ------------
   const int HoWo = p.Ho * p.Wo;
@@ -159,8 +161,8 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   int a_iy[KS == 7 ? APASS : 1], a_ix[KS == 7 ? APASS : 1];
 #pragma unroll
   for (int pp = 0; pp < APASS; ++pp) {
-    const int m = m0 + lrow + 32 * pp;
-    const bool ok = m < p.M;
+    const int m = m0 + lrow + LRP * pp;
+    const bool ok = m < p.m_end;
     const int mm = ok ? m : m0;
     const int n = mm / HoWo;
     const int rem = mm - n * HoWo;
@@ -196,7 +198,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   }
   unsigned b_off[BPASS];
 #pragma unroll
-  for (int pp = 0; pp < BPASS; ++pp) b_off[pp] = (unsigned)((lrow + 32 * pp) * p.Kp * EB + chunk * 16);
+  for (int pp = 0; pp < BPASS; ++pp) b_off[pp] = (unsigned)((lrow + LRP * pp) * p.Kp * EB + chunk * 16);
 
   f32x4 ra[APASS], rb[BPASS];
   const int nk1 = DUAL ? p.K1 / KC : 0;
@@ -271,9 +273,9 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   auto lstore_item = [&](int buf, int item) {
     float *As = smem + buf * (BM + BN) * kLds;
     if (item < APASS)
-      *reinterpret_cast<f32x4 *>(As + (lrow + 32 * item) * kLds + chunk * 4) = ra[item];
+      *reinterpret_cast<f32x4 *>(As + (lrow + LRP * item) * kLds + chunk * 4) = ra[item];
     else
-      *reinterpret_cast<f32x4 *>(As + BM * kLds + (lrow + 32 * (item - APASS)) * kLds + chunk * 4) = rb[item - APASS];
+      *reinterpret_cast<f32x4 *>(As + BM * kLds + (lrow + LRP * (item - APASS)) * kLds + chunk * 4) = rb[item - APASS];
   };
 
   // LDS-DMA item: the same offsets as gload_item, but the 16 bytes of every lane land directly in LDS
@@ -444,13 +446,13 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
   // row-major 16-B mapping, so its HBM latency hides under the MFMAs.  Rows past M read as zeros.
   constexpr int EW = (X3 || BF) ? 8 : 4;  // channels per thread per pass (split: one 32-byte group; bf16: 16 bytes)
   constexpr int TPR = BN / EW;         // threads per output row
-  constexpr int RPP = 256 / TPR;       // rows per pass
+  constexpr int RPP = NT / TPR;        // rows per pass
   constexpr int EPASS = BM / RPP;
   const int ecol = (tid % TPR) * EW, erow = tid / TPR;
   f32x4 rres[(RES && !X3 && !BF) ? EPASS : 1];
   u32x4 rres_h[(RES && (X3 || BF)) ? EPASS : 1], rres_l[(RES && X3) ? EPASS : 1];
   if (RES && (X3 || BF)) {
-    const size_t r_bytes = ((size_t)p.M - m0) * p.Cout * EB;
+    const size_t r_bytes = ((size_t)p.m_end - m0) * p.Cout * EB;
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.res) + (size_t)m0 * p.Cout * EB), 0,
         (int)(r_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : r_bytes), 0x00020000);
@@ -462,7 +464,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
     }
   }
   if (RES && !X3 && !BF) {
-    const size_t r_bytes = ((size_t)p.M - m0) * p.Cout * 4;
+    const size_t r_bytes = ((size_t)p.m_end - m0) * p.Cout * 4;
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.res + (size_t)m0 * p.Cout), 0,
         (int)(r_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : r_bytes), 0x00020000);
@@ -645,7 +647,7 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
 
   // Stores go through a descriptor that ends at row M: rows past the end are dropped by the range
   // check, which keeps the epilogue branch-free (no per-pass wait on earlier stores).
-  const size_t y_bytes = ((size_t)p.M - m0) * p.Cout * EB;
+  const size_t y_bytes = ((size_t)p.m_end - m0) * p.Cout * EB;
   const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char *>(p.y) + (size_t)m0 * p.Cout * EB, 0,
       (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
@@ -716,24 +718,24 @@ __global__ void __launch_bounds__(256) conv_igemm(const ConvParams p) {
 
 template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES>
 static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
-  p.ntm = (p.M + BM - 1) / BM;
+  p.ntm = (p.m_end - p.m_begin + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   const dim3 grid((unsigned)(p.ntm * p.ntn));
   if constexpr (KS == 1 && !SHIFT && !RES) {
     if (p.x2) {
       if (p.prec == kPrecBf16x3)
-        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecBf16x3, true>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecBf16x3, true>), grid, dim3(64 * WGM * WGN), 0, s, p);
       else if (p.prec == kPrecBf16)
-        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecBf16, true>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecBf16, true>), grid, dim3(64 * WGM * WGN), 0, s, p);
       else
-        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecF32, true>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecF32, true>), grid, dim3(64 * WGM * WGN), 0, s, p);
       return hipGetLastError();
     }
   }
   if (p.prec == kPrecBf16x3)
-    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16x3>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16x3>), grid, dim3(64 * WGM * WGN), 0, s, p);
   else if (p.prec == kPrecBf16)
-    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16>), grid, dim3(64 * WGM * WGN), 0, s, p);
   else {
     // fp32 64x64 pipeline variant: 0 = two LDS buffers, 1 = register-resident K-step (default), 2 = the same
     // fed by LDS-DMA.  All three accumulate in the same order (bit-identical results); measured within
@@ -741,11 +743,11 @@ static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
     const char *rk_env = getenv("TSM_CONV_RK");
     const int rk = rk_env ? atoi(rk_env) : 1;
     if (BM == 64 && BN == 64 && rk == 0)
-      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32, false, 0>), grid, dim3(256), 0, s, p);
+      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32, false, 0>), grid, dim3(64 * WGM * WGN), 0, s, p);
     else if (BM == 64 && BN == 64 && rk == 2)
-      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32, false, 2>), grid, dim3(256), 0, s, p);
+      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32, false, 2>), grid, dim3(64 * WGM * WGN), 0, s, p);
     else
-      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32>), grid, dim3(256), 0, s, p);
+      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32>), grid, dim3(64 * WGM * WGN), 0, s, p);
   }
   return hipGetLastError();
 }
@@ -764,8 +766,8 @@ void conv_tile_shape(const ConvParams &p, int *bm, int *bn) {
   static const char *force = getenv("TSM_CONV_TILE");
   if (force) {
     int fm = 0, fn = 0;
-    if (sscanf(force, "%dx%d", &fm, &fn) == 2 && (fm == 128 || fm == 64) && (fn == 128 || fn == 64) &&
-        !(fm == 64 && fn == 128) && p.Cout % fn == 0) {
+    if (sscanf(force, "%dx%d", &fm, &fn) == 2 && p.Cout % fn == 0 &&
+        ((fm == 128 && (fn == 128 || fn == 64)) || (fm == 64 && fn == 64) || (fm == 32 && fn == 32 && p.prec == kPrecF32))) {
       BM = fm;
       BN = fn;
     }
@@ -779,8 +781,14 @@ bool conv_tile_valid(const ConvParams &p, int tile) {
     case kTile128x128: return p.Cout % 128 == 0;
     case kTile128x64:
     case kTile64x64: return p.Cout % 64 == 0;
+    case kTile32x32: return p.Cout % 32 == 0 && p.prec == kPrecF32;  // single-wave tiles: fp32 only
     default: return false;
   }
+}
+
+void conv_tile_dims(int tile, int *bm, int *bn) {
+  *bm = tile == kTile32x32 ? 32 : (tile == kTile64x64 ? 64 : 128);
+  *bn = tile == kTile32x32 ? 32 : (tile == kTile128x128 ? 128 : 64);
 }
 
 template <int KS, bool SHIFT, bool RES>
@@ -789,15 +797,24 @@ static hipError_t launch_conv_ks(const ConvParams &p, hipStream_t s) {
   conv_tile_shape(p, &bm, &bn);
   if (p.tile != kTileAuto) {
     if (!conv_tile_valid(p, p.tile)) return hipErrorInvalidValue;
-    bm = p.tile == kTile64x64 ? 64 : 128;
-    bn = p.tile == kTile128x128 ? 128 : 64;
+    conv_tile_dims(p.tile, &bm, &bn);
+  }
+  if (bm == 32 && bn == 32) {
+    if (p.prec != kPrecF32) return hipErrorInvalidValue;
+    return launch_conv_t<32, 32, 1, 1, KS, SHIFT, RES>(p, s);
   }
   if (bm == 128 && bn == 128) return launch_conv_t<128, 128, 2, 2, KS, SHIFT, RES>(p, s);
   if (bm == 128 && bn == 64) return launch_conv_t<128, 64, 2, 2, KS, SHIFT, RES>(p, s);
   return launch_conv_t<64, 64, 2, 2, KS, SHIFT, RES>(p, s);
 }
 
-hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s) {
+hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
+  ConvParams p = p_in;
+  if (p.m_end <= 0) {  // whole problem
+    p.m_begin = 0;
+    p.m_end = p.M;
+  }
+  if (p.m_begin < 0 || p.m_begin >= p.m_end || p.m_end > p.M || p.m_begin % 32 != 0) return hipErrorInvalidValue;
   const int kc = p.prec == kPrecBf16 ? 64 : kBK;  // channels per K-step
   if (p.Cout % 64 != 0 || p.Kp % kc != 0 || p.M <= 0) return hipErrorInvalidValue;
   if ((1 << p.logC4) * 4 != p.C) return hipErrorInvalidValue;

@@ -184,7 +184,14 @@ class TsmEngine:
                 names += ([p + '.downsample'] if b == 0 else []) + [p + '.conv1', p + '.conv2', p + '.conv3']
         return names + ['head']
 
-    TILE_NAMES = {0: 'heuristic', 1: '128x128', 2: '128x64', 3: '64x64'}
+    TILE_NAMES = {0: 'heuristic', 1: '128x128', 2: '128x64', 3: '64x64', 4: '32x32'}
+
+    @classmethod
+    def tile_name(cls, code: int) -> str:
+        """``main + 16 * tail``: e.g. '64x64+32x32' = coarse 64x64 tiles for the rows that fill whole rounds
+        of the chip, single-wave 32x32 tiles (second stream) for the remaining rows."""
+        main, tail = code & 15, code >> 4
+        return cls.TILE_NAMES[main] + ('+' + cls.TILE_NAMES[tail] if tail else '')
 
     def conv_tiles(self, n_clips: int) -> Dict[str, str]:
         """Tile shape the autotuner chose per conv launch for an ``n_clips`` forward."""
@@ -193,7 +200,7 @@ class TsmEngine:
         _lib.check(self._lib.tsm_conv_tiles(self._h, n_clips, buf, 64, C.byref(n)), self._h)
         names = [k for k in self.launch_names() if k not in ('pack_input', 'maxpool', 'head')]
         assert n.value == len(names)
-        return {k: self.TILE_NAMES[buf[i]] for i, k in enumerate(names)}
+        return {k: self.tile_name(buf[i]) for i, k in enumerate(names)}
 
     def set_layer_timing(self, n_forwards: int, only_conv3x3: bool = False) -> None:
         _lib.check(self._lib.tsm_set_layer_timing(self._h, n_forwards, int(only_conv3x3)), self._h)
