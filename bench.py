@@ -111,7 +111,6 @@ def main():
                     help='f32: exact-fp32 MFMA; bf16x3: split-bf16 storage, 3 bf16 MFMAs per product')
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 

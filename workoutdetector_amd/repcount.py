@@ -7,7 +7,7 @@ Counterpart of ``RepcountHelper.get_rep_data`` / ``eval_count`` and ``RepcountIt
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import pandas as pd
