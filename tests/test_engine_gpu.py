@@ -124,7 +124,8 @@ def test_autotuned_tiles_are_bitwise_invariant(hip_lib, sd0, monkeypatch):
     outs = {}
     for name, env in [('tuned', {}), ('heuristic', {'TSM_AUTOTUNE': '0'}),
                       ('64x64', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '64x64'}),
-                      ('32x32', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '32x32'})]:
+                      ('32x32', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '32x32'}),
+                      ('128x128w8', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '128x128w8'})]:
         for k in ('TSM_AUTOTUNE', 'TSM_CONV_TILE'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -136,6 +137,7 @@ def test_autotuned_tiles_are_bitwise_invariant(hip_lib, sd0, monkeypatch):
         eng.close()
     assert np.array_equal(outs['tuned'], outs['heuristic'])
     assert np.array_equal(outs['tuned'], outs['64x64']) and np.array_equal(outs['tuned'], outs['32x32'])
+    assert np.array_equal(outs['tuned'], outs['128x128w8'])
 
 
 def test_create_model_from_checkpoint_and_onnx(hip_lib, sd0, tmp_path):

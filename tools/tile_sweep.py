@@ -27,7 +27,7 @@ print(json.dumps({k: sorted(v)[len(v)//2] for k, v in acc.items()}))
 ''' % ROOT
 
 res = {}
-for tile in ['default', '64x64', '32x32', 'code67']:
+for tile in os.environ.get('TSM_SWEEP_TILES', 'default,128x128,128x64,64x64').split(','):
     env = dict(os.environ)
     env['TSM_AUTOTUNE'] = '1' if tile == 'default' else '0'
     if len(sys.argv) > 1:

@@ -37,7 +37,11 @@ struct ConvParams {
 
 enum ConvPrec { kPrecF32 = 0, kPrecBf16x3 = 1, kPrecBf16 = 2 };
 
-enum ConvTile { kTileAuto = 0, kTile128x128 = 1, kTile128x64 = 2, kTile64x64 = 3, kTile32x32 = 4, kNumTiles = 5 };
+enum ConvTile {
+  kTileAuto = 0, kTile128x128 = 1, kTile128x64 = 2, kTile64x64 = 3, kTile32x32 = 4,
+  kTile128x128w8 = 5,  // 128x128 on 8 waves (512 threads): same LDS as kTile128x128, twice the waves per SIMD
+  kNumTiles = 6
+};
 void conv_tile_dims(int tile, int *bm, int *bn);
 // Is `tile` usable for this problem (Cout divisibility)?
 bool conv_tile_valid(const ConvParams &p, int tile);

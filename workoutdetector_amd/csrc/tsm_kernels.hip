@@ -15,6 +15,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace tsm {
 
@@ -85,7 +86,8 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 //                accumulation: relative error ~2^-17 per product, three MFMAs at 16x the fp32-MFMA rate.
 template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false, int RKT = 1>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p) {
-  static_assert(WGM * WGN == 4 || WGM * WGN == 1, "4 waves per workgroup, or 1 (32x32 tail / small-M tiles)");
+  static_assert(WGM * WGN == 4 || WGM * WGN == 1 || WGM * WGN == 8,
+                "4 waves per workgroup, 1 (32x32 small-M tiles) or 8 (128x128 with 4 waves per SIMD at 2 workgroups/CU)");
   constexpr int NT = 64 * WGM * WGN;   // threads per workgroup
   constexpr int LRP = NT / 8;          // loader rows per pass (8 threads x 16 bytes per 128-byte row)
   static_assert(!DUAL || (KS == 1 && !SHIFT && !RES), "K-concatenated second source: plain 1x1 convs only");
@@ -782,19 +784,25 @@ bool conv_tile_valid(const ConvParams &p, int tile) {
     case kTile128x64:
     case kTile64x64: return p.Cout % 64 == 0;
     case kTile32x32: return p.Cout % 32 == 0 && p.prec == kPrecF32;  // single-wave tiles: fp32 only
+    case kTile128x128w8: return p.Cout % 128 == 0;
     default: return false;
   }
 }
 
 void conv_tile_dims(int tile, int *bm, int *bn) {
   *bm = tile == kTile32x32 ? 32 : (tile == kTile64x64 ? 64 : 128);
-  *bn = tile == kTile32x32 ? 32 : (tile == kTile128x128 ? 128 : 64);
+  *bn = tile == kTile32x32 ? 32 : ((tile == kTile128x128 || tile == kTile128x128w8) ? 128 : 64);
 }
 
 template <int KS, bool SHIFT, bool RES>
-static hipError_t launch_conv_ks(const ConvParams &p, hipStream_t s) {
+static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
+  ConvParams p = p_in;
   int bm, bn;
   conv_tile_shape(p, &bm, &bn);
+  if (p.tile == kTileAuto) {  // tuning hook: TSM_CONV_TILE=128x128w8 forces the 8-wave form where it is valid
+    const char *force = getenv("TSM_CONV_TILE");
+    if (force && strcmp(force, "128x128w8") == 0 && conv_tile_valid(p, kTile128x128w8)) p.tile = kTile128x128w8;
+  }
   if (p.tile != kTileAuto) {
     if (!conv_tile_valid(p, p.tile)) return hipErrorInvalidValue;
     conv_tile_dims(p.tile, &bm, &bn);
@@ -803,6 +811,7 @@ static hipError_t launch_conv_ks(const ConvParams &p, hipStream_t s) {
     if (p.prec != kPrecF32) return hipErrorInvalidValue;
     return launch_conv_t<32, 32, 1, 1, KS, SHIFT, RES>(p, s);
   }
+  if (bm == 128 && bn == 128 && p.tile == kTile128x128w8) return launch_conv_t<128, 128, 4, 2, KS, SHIFT, RES>(p, s);
   if (bm == 128 && bn == 128) return launch_conv_t<128, 128, 2, 2, KS, SHIFT, RES>(p, s);
   if (bm == 128 && bn == 64) return launch_conv_t<128, 64, 2, 2, KS, SHIFT, RES>(p, s);
   return launch_conv_t<64, 64, 2, 2, KS, SHIFT, RES>(p, s);
