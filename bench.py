@@ -122,10 +122,18 @@ def main():
             raise SystemExit('launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the product path)'
+    # Rehearsal hook for boxes with fewer GPUs than ranks (TSM_BENCH_REHEARSAL=1): all ranks share cuda:0 and
+    # the process group is gloo.  Exercises the N > 1 control flow only; its numbers mean nothing.
+    rehearsal = os.environ.get('TSM_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from workoutdetector_amd.build import build_library
     if rank == 0:
