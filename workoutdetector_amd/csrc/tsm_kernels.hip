@@ -1,13 +1,19 @@
 // Hand-written CDNA4 (gfx950) kernels for the TSM-ResNet50 clip forward.
 //
-//   conv_igemm_f32   implicit-GEMM convolution (1x1 / 3x3 / 7x7, stride 1|2) on the exact-fp32 MFMA
-//                    (v_mfma_f32_32x32x2_f32), NHWC activations, LDS-staged A (im2col rows built on
-//                    the fly, temporal shift fused into the loader) and B (packed weights),
-//                    epilogue = folded-BN bias + residual + ReLU.
-//   pack_input       [N,3,H,W] or [N,H,W,3] -> NHWC4 (zero 4th channel) so every stem tap is one 16-B load
-//   maxpool3x3s2     NHWC
-//   temporal_shift   stand-alone NHWC shift (tests; the forward uses the fused loader)
-//   head             global avg-pool + FC + mean over segments
+//   conv_igemm       implicit-GEMM convolution (1x1 / 3x3 / 7x7, stride 1|2), NHWC activations, LDS-staged A
+//                    (im2col rows built on the fly, temporal shift fused into the loader) and B (packed
+//                    weights), epilogue = folded-BN bias + residual + ReLU.  Template axes: tile shape and wave
+//                    layout (128x128 on 4 or 8 waves, 128x64, 64x64, 32x32 on one wave), KS, SHIFT (fused
+//                    temporal shift), RES (residual prefetched under the K loop), PREC (exact-fp32 MFMA /
+//                    split-bf16 x3 / bf16), DUAL (second A source concatenated along K = conv3 + downsample in
+//                    one GEMM), RKT (fp32 64x64 pipeline: 2 LDS buffers / register-resident K-step / LDS-DMA).
+//                    Every variant accumulates each output in the same k order: results are bit-identical
+//                    across tile shapes and pipelines of one precision.
+//   pack_input       [N,3,H,W] or [N,H,W,3] fp32 -> one channel group per pixel in the engine's storage format
+//   preprocess       fused test transform: uint8/fp32 frames -> resize 256 / crop 224 / normalise -> packed input
+//   maxpool3x3s2     NHWC, any storage format
+//   temporal_shift   stand-alone NHWC fp32 shift (tests; the forward uses the fused loader)
+//   head             per-frame global avg-pool, then mean over segments + FC
 //
 // Reference semantics: workoutdetector/models/tsm.py:35-50 (shift), :409-419 (forward/head);
 // torchvision-0.13 ResNet-50 v1.5 Bottleneck for the conv stack.
@@ -32,8 +38,9 @@ constexpr int kBK = 32;
 // ---------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution.  GEMM view: Y[M, Cout] = A[M, K] * W^T[K, Cout],
 //   M = N*Ho*Wo output pixels, K = KS*KS*C ordered (ky, kx, c) so that NHWC input rows are
-//   contiguous along K within one tap.  One workgroup = 256 threads = 4 waves (WGM x WGN), block
-//   tile BM x BN, K-step 32.  Each wave owns (BM/WGM) x (BN/WGN) as TM x TN MFMA tiles of 32x32.
+//   contiguous along K within one tap.  One workgroup = WGM x WGN waves (4, 8 or 1), block tile
+//   BM x BN, K-step = one 128-byte row per operand (32 fp32 or split channels, 64 bf16 channels).
+//   Each wave owns (BM/WGM) x (BN/WGN) as TM x TN MFMA tiles of 32x32.
 //
 // MFMA operand order: v_mfma_f32_32x32x2_f32 takes A[i = lane&31][k = lane>>5] and
 // B[k = lane>>5][j = lane&31].  The reduction order inside K is free as long as A and B agree, so
