@@ -10,7 +10,7 @@ every rank runs its own batch (weak scaling) and the only exchange is the RCCL a
 logits, which is inside the timed step.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant kernel is the conv_igemm_f32<BM,BN,2,2,3,false,false> instantiation the engine's
+  roofline      the dominant kernel is the conv_igemm<BM,BN,WGM,WGN,3,false,false,PREC,false,RKT> instantiation the engine's
                 autotuner picked for the 3x3 convolutions of layer2..layer4 (13 launches per forward, one
                 third of the forward's time; if the tuner split them over two tile shapes, the shape with
                 the larger total).  Every one of
@@ -214,7 +214,7 @@ def main():
         assert len(dom_gflop) == 1, 'every 3x3 conv of ResNet-50 does the same work per frame'
         dom_gflop = dom_gflop.pop()
         # The engine tunes the tile shape per layer, so the 3x3 convs may run on more than one
-        # instantiation of conv_igemm_f32: the dominant kernel is the instantiation with the most time.
+        # instantiation of conv_igemm: the dominant kernel is the instantiation with the most time.
         groups = {}
         for r in dom:
             groups.setdefault(tiles[r['name']], []).extend(d[r['name']] for d in per_launch)
