@@ -77,3 +77,21 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h')):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+
+
+def _build_c_smoke(tmp_path):
+    from workoutdetector_amd.build import LIB_PATH, PKG_DIR
+    exe = str(tmp_path / 'abi_c_smoke')
+    cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'),
+           os.path.join(ROOT, 'tests', 'abi_c_smoke.c'), '-o', exe, LIB_PATH, f'-Wl,-rpath,{PKG_DIR}']
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_header_is_plain_c_and_links(lib, tmp_path):
+    """include/tsm_hip.h compiles as C99 with -Wall -Werror and a C program links against the library; the
+    error paths it exercises need no GPU."""
+    exe = _build_c_smoke(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert 'error paths ok' in out.stdout

@@ -181,3 +181,13 @@ def test_fp32_pipeline_variants_are_bit_identical(hip_lib, sd0, monkeypatch):
     assert np.array_equal(taps['0'], taps['1']) and np.array_equal(taps['0'], taps['2'])
     want = tsm_oracle.tsm_forward(sd0, torch.from_numpy(x)).numpy()
     assert_close(outs['2'], want, rtol=1e-3, atol_scale=1e-4, what='dma variant vs oracle')
+
+
+def test_c_program_runs_a_forward(hip_lib, tmp_path):
+    """The engine driven from plain C (tests/abi_c_smoke.c): all-zero convs -> logits == fc.bias exactly."""
+    import subprocess
+    from tests.test_abi import _build_c_smoke
+    exe = _build_c_smoke(tmp_path)
+    out = subprocess.run([exe, 'run'], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'forward ok' in out.stdout

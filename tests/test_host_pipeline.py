@@ -168,3 +168,32 @@ def test_read_video_npy_and_missing_decoder(tmp_path):
     except ImportError:
         with pytest.raises(RuntimeError, match='no video decoder'):
             ic.read_video('/nonexistent/video.mp4')
+
+
+def test_stream_batcher_matches_per_stream_counting():
+    """Many interleaved streams through one batched model call == each stream counted on its own
+    (count_by_video_model); frame sizes differ between streams; max_batch splits a step."""
+    from workoutdetector_amd.streaming import StreamBatcher
+    vids = {'a': synthetic_video(1, 90, 30, 40, period=16), 'b': synthetic_video(2, 61, 36, 36, period=20),
+            'c': synthetic_video(3, 40, 30, 40, period=12)}
+    model = StubModel(gain=8.0)
+    sb = StreamBatcher(model, max_batch=3)
+    events = {k: [] for k in vids}
+    for t in range(90):                                  # frames arrive interleaved; step every 10 ticks
+        for k, v in vids.items():
+            if t < len(v):
+                sb.push(k, v[t])
+        if t % 10 == 9:
+            for k, ev in sb.step().items():
+                events[k] += ev
+    for k, ev in sb.step().items():
+        events[k] += ev
+    assert sb.ready() == 0 and model.calls < sum(len(v) // 8 for v in vids.values())    # windows were batched
+    for k, v in vids.items():
+        seen = []
+        want = ic.count_by_video_model(StubModel(gain=8.0), iter(v), on_window=lambda i, s, c: seen.append((i, s, c)))
+        assert events[k] == seen
+        assert sb.result(k) == want and sb.close(k) == want
+    assert not sb.streams
+    with pytest.raises(ValueError):
+        sb.push('d', np.zeros((4, 4, 3), np.float32))

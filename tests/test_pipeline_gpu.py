@@ -108,3 +108,37 @@ def test_inference_dataset_on_gpu_engine(probe_engine, tmp_path, golden_dir):
         want = tsm_oracle.tsm_forward(sd, transform_oracle.clip_to_input(transform_oracle.make_clip(vid, s)))[0]
         got = np.float32([d['scores'][str(s)][str(c)] for c in range(12)])
         assert_close(got, want.numpy(), rtol=1e-3, atol_scale=1e-4, what=f'clip {s}')
+
+
+def test_stream_batcher_on_gpu_engine(probe_engine):
+    """several live streams of different frame sizes share one engine; windows of all
+    streams go through the fused HIP transform + one tsm_forward per step.  Exact: batched == one window at a
+    time (batch invariance); the per-stream counts equal an offline pred_to_count of that stream's states."""
+    from workoutdetector_amd.counting import pred_to_count
+    from workoutdetector_amd.streaming import StreamBatcher
+    eng, _ = probe_engine
+    vids = {'a': synthetic_video(31, 240, 90, 52, period=24), 'b': synthetic_video(32, 200, 120, 68, period=32),
+            'c': synthetic_video(33, 168, 90, 52, period=20)}
+
+    def play(max_batch, every):
+        sb = StreamBatcher(eng, max_batch=max_batch)
+        ev = {k: [] for k in vids}
+        for t in range(240):
+            for k, v in vids.items():
+                if t < len(v):
+                    sb.push(k, v[t])
+            if t % every == every - 1:
+                for k, e in sb.step().items():
+                    ev[k] += e
+        for k, e in sb.step().items():
+            ev[k] += e
+        return ev, {k: sb.result(k) for k in vids}
+
+    ev32, res32 = play(32, 40)          # 5 windows x 3 streams per step -> batches of up to 15 mixed-size windows
+    ev1, res1 = play(1, 8)
+    assert ev32 == ev1 and res32 == res1
+    for k, v in vids.items():
+        states = [s for _, s, _ in ev32[k]]
+        assert len(states) == len(v) // 8
+        assert res32[k] == pred_to_count(states, 8) == counting_oracle.pred_to_count(states, 8)
+    assert res32['a'][0] >= 5 and res32['b'][0] >= 3

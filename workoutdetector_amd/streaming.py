@@ -1,0 +1,135 @@
+"""Online repetition counting for many concurrent frame streams on one engine.
+
+Counterpart of the reference's streaming consumers of the video model -- ``count_by_video_model``
+(workoutdetector/utils/inference_count.py:285-339: a ``deque(maxlen=8)``, one inference per 8 queued
+frames, ``input_queue.clear()``) and the WebSocket loop of ``app/inference.py:87-111`` / ``app/server.py:85-100``
+(one client = one stream, 8 frames per window) -- re-shaped for the GPU: every stream only queues frames;
+``StreamBatcher.step()`` collects the windows that are complete across ALL streams and pushes them through the
+engine as ONE batch (fused HIP transform + ``tsm_forward``), then feeds each stream's incremental counter.
+The reference runs one blocking batch-1 ``session.run`` per client window.
+
+No transport here (the WebSocket/HTTP front is outside the hot path): a server
+calls ``push`` from its receive loop and ``step`` on a timer or whenever ``ready()`` is large enough.
+"""
+from __future__ import annotations
+
+from collections import deque
+from dataclasses import dataclass, field
+from typing import Callable, Deque, Dict, Hashable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .counting import RepCounter, scores_to_preds
+from .inference_count import NUM_SEGMENTS, _engine_device
+from .transform import TestTransform, build_test_transform
+
+
+@dataclass
+class StreamState:
+    counter: RepCounter
+    frames: List[np.ndarray] = field(default_factory=list)        # frames of the window being filled
+    windows: Deque[np.ndarray] = field(default_factory=deque)     # complete [8,H,W,3] uint8 windows not yet run
+    states: List[int] = field(default_factory=list)               # one state per processed window
+    frames_seen: int = 0
+
+
+class StreamBatcher:
+    """``push(stream_id, frame)`` HWC uint8 RGB frames; ``step()`` runs every complete 8-frame window of every
+    stream in batches of at most ``max_batch`` and returns ``{stream_id: [(window_index, state, count), ...]}``.
+
+    Windows are non-overlapping with stride 8 like the reference's streaming loop; ``softmax``/``threshold``
+    follow utils/eval.py:153-164; frame sizes may differ between streams (windows are transformed per source
+    resolution, then batched at 224x224)."""
+
+    def __init__(self, model, threshold: float = 0.5, softmax: bool = True, step: int = 8, max_batch: int = 32,
+                 transform: Optional[TestTransform] = None,
+                 on_window: Optional[Callable[[Hashable, int, int, int], None]] = None):
+        self.model = model
+        self.threshold, self.softmax, self.step_frames = threshold, softmax, step
+        self.max_batch = max_batch
+        self.transform = transform or build_test_transform(False)
+        self.on_window = on_window
+        self.streams: Dict[Hashable, StreamState] = {}
+
+    # ---- ingest -------------------------------------------------------------------------------------------
+    def open(self, stream_id: Hashable) -> StreamState:
+        if stream_id not in self.streams:
+            self.streams[stream_id] = StreamState(RepCounter(self.step_frames))
+        return self.streams[stream_id]
+
+    def push(self, stream_id: Hashable, frame) -> None:
+        st = self.open(stream_id)
+        arr = np.asarray(frame)
+        if arr.dtype != np.uint8 or arr.ndim != 3 or arr.shape[2] != 3:
+            raise ValueError(f'frame must be uint8 [H,W,3], got {arr.dtype} {arr.shape}')
+        if st.frames and st.frames[0].shape != arr.shape:
+            raise ValueError('frame size changed inside a window')
+        st.frames.append(arr)
+        st.frames_seen += 1
+        if len(st.frames) == NUM_SEGMENTS:
+            st.windows.append(np.stack(st.frames))
+            st.frames = []                      # input_queue.clear() of the reference
+
+    def ready(self) -> int:
+        return sum(len(s.windows) for s in self.streams.values())
+
+    def close(self, stream_id: Hashable) -> Tuple[int, List[int]]:
+        """Drop a stream (an incomplete last window is discarded, like the reference) -> (count, reps)."""
+        st = self.streams.pop(stream_id)
+        return st.counter.count, list(st.counter.reps)
+
+    def result(self, stream_id: Hashable) -> Tuple[int, List[int]]:
+        st = self.streams[stream_id]
+        return st.counter.count, list(st.counter.reps)
+
+    # ---- compute ------------------------------------------------------------------------------------------
+    def _logits(self, windows: List[np.ndarray]) -> np.ndarray:
+        """[n,8,H,W,3] uint8 windows (possibly of different sizes) -> raw logits [n, num_class]."""
+        dev = _engine_device(self.model)
+        if dev is not None and hasattr(self.model, 'packed_layout'):
+            from .engine import preprocess_frames
+            layout = self.model.packed_layout
+            by_shape: Dict[Tuple[int, ...], List[int]] = {}
+            for i, w in enumerate(windows):     # one upload + one transform launch per source resolution
+                by_shape.setdefault(w.shape, []).append(i)
+            clips = None
+            for shape, idx in by_shape.items():
+                fr = torch.from_numpy(np.concatenate([windows[i] for i in idx])).to(dev, non_blocking=True)
+                pk = preprocess_frames(fr, resize=self.transform.size, crop=self.transform.crop,
+                                       scale_255=self.transform.scale_255, layout=layout)
+                pk = pk.view((len(idx), NUM_SEGMENTS) + tuple(pk.shape[1:]))
+                if len(by_shape) == 1:
+                    clips = pk
+                else:
+                    if clips is None:
+                        clips = torch.empty((len(windows),) + tuple(pk.shape[1:]), dtype=pk.dtype, device=dev)
+                    clips[torch.tensor(idx, device=dev)] = pk
+            return self.model.forward_device(clips.contiguous(), layout=layout).cpu().numpy()
+        xs = [self.transform(torch.from_numpy(w).permute(0, 3, 1, 2).float()) for w in windows]
+        name = self.model.get_inputs()[0].name
+        return np.asarray(self.model.run(None, {name: torch.stack(xs).numpy()})[0])
+
+    def step(self) -> Dict[Hashable, List[Tuple[int, int, int]]]:
+        """Run all complete windows (oldest first, round-robin over streams) and update the counters."""
+        out: Dict[Hashable, List[Tuple[int, int, int]]] = {}
+        while self.ready():
+            batch: List[Tuple[Hashable, np.ndarray]] = []
+            progressed = True
+            while len(batch) < self.max_batch and progressed:   # round-robin keeps per-stream order and fairness
+                progressed = False
+                for sid, st in self.streams.items():
+                    if st.windows and len(batch) < self.max_batch:
+                        batch.append((sid, st.windows.popleft()))
+                        progressed = True
+            logits = self._logits([w for _, w in batch])
+            states = scores_to_preds(logits.tolist(), threshold=self.threshold, softmax=self.softmax)
+            for (sid, _), state in zip(batch, states):
+                st = self.streams[sid]
+                widx = len(st.states)
+                st.states.append(state)
+                count = st.counter.push(state)
+                out.setdefault(sid, []).append((widx, state, count))
+                if self.on_window is not None:
+                    self.on_window(sid, widx, state, count)
+        return out
