@@ -191,10 +191,19 @@ def main():
         t_max = torch.tensor([elapsed], device='cuda')
         if world > 1:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+            # the exchange step on its own ("all-gather us"), outside the timed region
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                all_gather_logits(logits)
+            torch.cuda.synchronize()
+            exchange_us[dtype] = 1e6 * (time.perf_counter() - t0) / 20
         tiles = eng.conv_tiles(B)
         eng.close()
         return float(t_max.item()), per_launch, sorted(fwd_ev_ms)[len(fwd_ev_ms) // 2], tiles
 
+    exchange_us = {}
     elapsed, per_launch, fwd_ms, tiles = run_mode(args.dtype, True)
     alt = None
     if not args.no_alt:
@@ -254,6 +263,10 @@ def main():
                          'forward_frac': round(fwd_achieved / peak, 4),
                          'forward_gflop': round(gflop * B, 3), 'forward_kernel_ms': round(fwd_ms, 4)},
         }
+        if world > 1:
+            line['exchange'] = {'collective': 'all_gather_into_tensor of f32[%d, 12] per rank (RCCL)' % B,
+                                'avg_us': round(exchange_us[args.dtype], 1),
+                                'note': 'back-to-back latency of the only data-path collective, measured outside the timed steps'}
         if alt is not None:
             a_dtype, a_elapsed, a_fwd = alt
             line['alt_precision'] = {

@@ -79,3 +79,24 @@ def test_bf16_engine_224_taps_and_packed_input(hip_lib, sd0, capsys):
     b = eng.run(None, {'input': ref_in.numpy()})[0]
     assert float(np.abs(a - b).max()) <= 2e-2 * float(np.abs(b).max())
     eng.close()
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3'])
+def test_tile_choice_is_bitwise_neutral_in_bf16_modes(hip_lib, sd0, monkeypatch, dtype):
+    """bf16 / split-bf16 engines: tuned, heuristic and forced tilings give bit-identical logits -- the k order of every output is tile-independent."""
+    from workoutdetector_amd.engine import TsmEngine
+    x = make_input(22, 3, 8, 96, 96)
+    outs = {}
+    for name, env in [('tuned', {}), ('heuristic', {'TSM_AUTOTUNE': '0'}),
+                      ('64x64', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '64x64'}),
+                      ('128x128', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '128x128'}),
+                      ('128x128w8', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '128x128w8'})]:
+        for k in ('TSM_AUTOTUNE', 'TSM_CONV_TILE'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = TsmEngine(height=96, width=96, max_clips=3, state_dict=sd0, dtype=dtype)
+        outs[name] = eng.run(None, {'input': x})[0]
+        eng.close()
+    for name in outs:
+        assert np.array_equal(outs['tuned'], outs[name]), name

@@ -1,6 +1,6 @@
 """Per-layer time and TFLOP/s of one forward from a rocprofv3 --kernel-trace CSV.
 
-    python tools/layer_times.py gpurun_out/prof1/runc/700_kernel_trace.csv [frames]
+    python tools/layer_times.py gpurun_out/prof1/runc/700_kernel_trace.csv|run_results.db [frames [size]]
 """
 import csv
 import sys
@@ -10,14 +10,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.tsm_oracle import layer_table  # noqa: E402
 
 
-def main(path, frames=256):
-    rows = list(csv.DictReader(open(path)))
+def read_rows(path):
+    """Rows with the CSV column names, from a kernel-trace CSV or a rocpd ``*_results.db``."""
+    if not path.endswith('.db'):
+        return list(csv.DictReader(open(path)))
+    import sqlite3
+    db = sqlite3.connect(path)
+    q = ('select name, start, end, grid_x, workgroup_x, vgpr_count, lds_size from kernels')
+    return [dict(Kernel_Name=n, Start_Timestamp=s, End_Timestamp=e, Grid_Size_X=g, Workgroup_Size_X=w, VGPR_Count=v,
+                 LDS=l) for n, s, e, g, w, v, l in db.execute(q)]
+
+
+def main(path, frames=256, size=224):
+    rows = read_rows(path)
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     names = [r['Kernel_Name'] for r in rows]
     idx = [i for i, n in enumerate(names) if 'pack_input' in n]
     fw = rows[idx[-2]:idx[-1]]
     convs = [r for r in fw if 'conv_' in r['Kernel_Name']]
-    byname = {r['name']: r for r in layer_table()}
+    byname = {r['name']: r for r in layer_table(size, size)}
     order = ['conv1']
     fused = len(convs) == 49          # conv3 + downsample of each stage's first block run as one launch
     for li, nb in enumerate((3, 4, 6, 3), 1):
@@ -44,4 +55,4 @@ def main(path, frames=256):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 256)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 256, int(sys.argv[3]) if len(sys.argv) > 3 else 224)

@@ -349,7 +349,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   auto conv = [&](int idx, tsm::ConvParams p, int ks, bool is3x3) -> int {
     if (!tuning) {
       int code = tiles ? (*tiles)[idx] : 0;
-      static const char *force_code = getenv("TSM_CONV_CODE");  // tuning hook: force one tile code everywhere
+      const char *force_code = getenv("TSM_CONV_CODE");  // tuning hook: force one tile code everywhere
       if (force_code && tsm::conv_tile_valid(p, atoi(force_code) & 15)) code = atoi(force_code);
       TSM_LAUNCH_K(e, s, is3x3, launch_code(p, ks, code));
       return TSM_OK;

@@ -772,7 +772,7 @@ void conv_tile_shape(const ConvParams &p, int *bm, int *bn) {
     BN = 64;
   }
   // Tuning hook (tools/ sweeps only): TSM_CONV_TILE=128x64 | 64x64 | 128x128 forces a shape.
-  static const char *force = getenv("TSM_CONV_TILE");
+  const char *force = getenv("TSM_CONV_TILE");  // read per launch so tests can switch it
   if (force) {
     int fm = 0, fn = 0;
     if (sscanf(force, "%dx%d", &fm, &fn) == 2 && p.Cout % fn == 0 &&

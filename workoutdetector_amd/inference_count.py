@@ -125,6 +125,31 @@ class StagedVideo:
     _pinned: Optional[torch.Tensor] = None
 
 
+class _PinnedPool:
+    """Reusable page-locked staging buffers.  Pinning fresh memory for every video costs a hipHostMalloc /
+    hipHostFree pair that serialises with the GPU queue; here a few flat byte buffers are grown geometrically
+    and handed out round-robin, each only after the H2D copy that last read it has completed."""
+
+    def __init__(self, slots: int = 3):
+        self.bufs: List[Optional[torch.Tensor]] = [None] * slots
+        self.busy: List[Optional[object]] = [None] * slots      # event of the last copy out of the slot
+        self.next = 0
+
+    def take(self, nbytes: int) -> Tuple[torch.Tensor, int]:
+        i = self.next
+        self.next = (i + 1) % len(self.bufs)
+        if self.busy[i] is not None:
+            self.busy[i].synchronize()
+            self.busy[i] = None
+        if self.bufs[i] is None or self.bufs[i].numel() < nbytes:
+            self.bufs[i] = None                                  # free before growing
+            self.bufs[i] = torch.empty(max(nbytes, 1 << 20) * 5 // 4, dtype=torch.uint8, pin_memory=True)
+        return self.bufs[i][:nbytes], i
+
+
+_pinned_pool = _PinnedPool()
+
+
 def stage_video(model, video_thwc_u8: torch.Tensor, clip_range: Optional[Tuple[int, int]] = None,
                 stream: Optional[object] = None) -> StagedVideo:
     """Slice the even frames a clip range samples and, for a TsmEngine, copy them to its GPU through a
@@ -142,7 +167,9 @@ def stage_video(model, video_thwc_u8: torch.Tensor, clip_range: Optional[Tuple[i
     dev = _engine_device(model)
     if dev is None or not hasattr(model, 'packed_layout'):
         return StagedVideo(total, lo, hi, f_lo, hw, even, False)
-    pinned = torch.empty((even.shape[0] + 1,) + tuple(even.shape[1:]), dtype=torch.uint8, pin_memory=True)
+    shape = (even.shape[0] + 1,) + tuple(even.shape[1:])
+    flat, slot = _pinned_pool.take(int(np.prod(shape)))
+    pinned = flat.view(shape)
     pinned[:-1].copy_(even)
     pinned[-1].zero_()              # the zero frame the padded tail clip reads
     ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
@@ -150,6 +177,7 @@ def stage_video(model, video_thwc_u8: torch.Tensor, clip_range: Optional[Tuple[i
         frames = pinned.to(dev, non_blocking=True)
         ready = torch.cuda.Event()
         ready.record()
+    _pinned_pool.busy[slot] = ready
     return StagedVideo(total, lo, hi, f_lo, hw, frames, True, ready, pinned)
 
 
