@@ -62,9 +62,12 @@ typedef enum tsm_layout {
   TSM_LAYOUT_NTHWC = 1, /* float32 [B,T,H,W,3]  -- decoder-native, skips the host permute */
   TSM_LAYOUT_NTHWC4 = 2, /* float32 [B,T,H,W,4]  -- what tsm_preprocess writes for a TSM_DTYPE_F32 engine
                             (4th channel 0); device memory only, consumed in place without a repack */
-  TSM_LAYOUT_NTHWC8S = 3, /* split-bf16 [B,T,H,W,8 channels] = 32 bytes per pixel, [hi x8 | lo x8] -- what
-                             tsm_preprocess writes for a TSM_DTYPE_BF16X3 engine; device memory only  */
-  TSM_LAYOUT_NTHWC8B = 4  /* bf16 [B,T,H,W,8 channels] = 16 bytes per pixel -- for a TSM_DTYPE_BF16 engine */
+  TSM_LAYOUT_NTHWC8S = 3, /* split-bf16 [B,T,H,ceil(W/2),8]: one 32-byte group [hi x8 | lo x8] per PIXEL PAIR,
+                             elements (pixel 2j: c0 c1 c2 0, pixel 2j+1: c0 c1 c2 0), an odd width ends in a
+                             zero pixel -- what tsm_preprocess writes for a TSM_DTYPE_BF16X3 engine (the 7x7
+                             stride-2 stem then reads 4 aligned pairs per kernel row); device memory only */
+  TSM_LAYOUT_NTHWC8B = 4  /* bf16 [B,T,H,ceil(W/2),8]: the same pixel pairs, 16 bytes per pair -- for a
+                             TSM_DTYPE_BF16 engine */
 } tsm_layout;
 
 typedef enum tsm_pixel { TSM_PIXEL_U8 = 0, TSM_PIXEL_F32 = 1 } tsm_pixel;
@@ -173,8 +176,8 @@ int tsm_maxpool3x3s2(const float *x, float *y, int32_t n, int32_t hi, int32_t wi
  *   -> Normalize(ImageNet)            workoutdetector/datasets/build.py:131-136
  * frames: [n, h, w, 3] decoder layout, TSM_PIXEL_U8 or TSM_PIXEL_F32 (values 0..255).
  * out:    out_layout TSM_LAYOUT_NTHWC4 -> [n, crop, crop, 4] fp32, TSM_LAYOUT_NTHWC8S -> split-bf16 /
- *         TSM_LAYOUT_NTHWC8B -> bf16 [n, crop, crop, 8 ch] (feed tsm_forward of an engine of the
- *         matching dtype directly) or TSM_LAYOUT_NTCHW -> [n, 3, crop, crop] fp32.
+ *         TSM_LAYOUT_NTHWC8B -> bf16 pixel pairs [n, crop, ceil(crop/2), 8] (feed tsm_forward of an engine
+ *         of the matching dtype directly) or TSM_LAYOUT_NTCHW -> [n, 3, crop, crop] fp32.
  * scale_255 = 0 reproduces the reference's inference_dataset, which never divides by 255
  * (utils/inference_count.py:412-414); 1 scales to [0,1] first. */
 int tsm_preprocess(const void *frames, int32_t pixel, int32_t n, int32_t h, int32_t w, float *out,

@@ -73,8 +73,8 @@ def test_bf16_engine_224_taps_and_packed_input(hip_lib, sd0, capsys):
         assert float(np.abs(eng.forward_tap(x, stage) - t).max()) <= 3e-2 * float(np.abs(t).max()), stage
     vid = torch.from_numpy(synthetic_video(3, 16, 120, 90))
     packed = preprocess_frames(vid.cuda(), layout=eng.packed_layout, scale_255=True)
-    assert eng.packed_layout == _lib.LAYOUT_NTHWC8B and tuple(packed.shape) == (16, 224, 224, 4)
-    a = eng.forward_device(packed.reshape(2, 8, 224, 224, 4), layout=_lib.LAYOUT_NTHWC8B).cpu().numpy()
+    assert eng.packed_layout == _lib.LAYOUT_NTHWC8B and tuple(packed.shape) == (16, 224, 112, 4)
+    a = eng.forward_device(packed.reshape(2, 8, 224, 112, 4), layout=_lib.LAYOUT_NTHWC8B).cpu().numpy()
     ref_in = transform_oracle.test_transform(vid.permute(0, 3, 1, 2).float(), scale_255=True).reshape(2, 8, 3, 224, 224)
     b = eng.run(None, {'input': ref_in.numpy()})[0]
     assert float(np.abs(a - b).max()) <= 2e-2 * float(np.abs(b).max())

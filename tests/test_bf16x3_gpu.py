@@ -85,8 +85,8 @@ def test_preprocess_split_layout_feeds_x3_engine(engine_x3):
     from tests._stub import synthetic_video
     vid = torch.from_numpy(synthetic_video(3, 16, 120, 90))
     packed = preprocess_frames(vid.cuda(), layout=engine_x3.packed_layout)
-    assert engine_x3.packed_layout == _lib.LAYOUT_NTHWC8S and tuple(packed.shape) == (16, 224, 224, 8)
-    a = engine_x3.forward_device(packed.reshape(2, 8, 224, 224, 8), layout=_lib.LAYOUT_NTHWC8S).cpu()
+    assert engine_x3.packed_layout == _lib.LAYOUT_NTHWC8S and tuple(packed.shape) == (16, 224, 112, 8)
+    a = engine_x3.forward_device(packed.reshape(2, 8, 224, 112, 8), layout=_lib.LAYOUT_NTHWC8S).cpu()
     want_in = transform_oracle.test_transform(vid.permute(0, 3, 1, 2).float()).reshape(2, 8, 3, 224, 224)
     b = engine_x3.run(None, {'input': want_in.numpy()})[0]
     assert_close(a.numpy(), b, rtol=1e-4, atol_scale=1e-4, what='packed split input')

@@ -47,3 +47,28 @@ def test_packed_layout_feeds_engine_like_nchw(hip_lib, sd0):
     with pytest.raises(TsmError):                                        # packed layout is device-only
         eng.forward_host(packed.cpu().numpy().reshape(2, 8, 224, 224, 4), layout=_lib.LAYOUT_NTHWC4)
     eng.close()
+
+
+@pytest.mark.parametrize('crop,resize', [(224, 256), (33, 40)])
+def test_pixel_pair_layouts_of_the_bf16_formats(hip_lib, crop, resize):
+    """TSM_LAYOUT_NTHWC8B / NTHWC8S: one 8-element group per pixel PAIR (pixel 2j: c0 c1 c2 0, pixel 2j+1: ...),
+    rows of ceil(crop/2) pairs, an odd crop ending in a zero pixel.  Decoded and compared with the fp32 NCHW
+    output of the same kernel: bf16 = fp32 rounded to 8 significand bits (RNE); split = hi + lo within 2^-16."""
+    from workoutdetector_amd import _lib
+    from workoutdetector_amd.engine import preprocess_frames
+    rng = np.random.default_rng(crop)
+    vid = torch.from_numpy(rng.integers(0, 256, size=(2, 90, 52, 3), dtype=np.uint8)).cuda()
+    want = preprocess_frames(vid, resize=resize, crop=crop, packed=False).cpu().permute(0, 2, 3, 1)   # [n,crop,crop,3]
+    pairs = (crop + 1) // 2
+    b = preprocess_frames(vid, resize=resize, crop=crop, layout=_lib.LAYOUT_NTHWC8B).cpu()
+    assert tuple(b.shape) == (2, crop, pairs, 4)
+    px = b.view(torch.bfloat16).reshape(2, crop, pairs * 2, 4).float()
+    assert torch.equal(px[:, :, :crop, :3], want.to(torch.bfloat16).float())
+    assert float(px[..., 3].abs().max()) == 0.0 and float(px[:, :, crop:].abs().max() if crop % 2 else 0.0) == 0.0
+    s = preprocess_frames(vid, resize=resize, crop=crop, layout=_lib.LAYOUT_NTHWC8S).cpu()
+    assert tuple(s.shape) == (2, crop, pairs, 8)
+    g = s.view(torch.bfloat16).reshape(2, crop, pairs, 2, 8).float()       # [hi x8 | lo x8] per pair
+    val = (g[:, :, :, 0] + g[:, :, :, 1]).reshape(2, crop, pairs * 2, 4)
+    assert torch.equal(g[:, :, :, 0].reshape(2, crop, pairs * 2, 4)[:, :, :crop, :3], want.to(torch.bfloat16).float())
+    err = (val[:, :, :crop, :3] - want).abs()
+    assert bool((err <= want.abs() * 2.0 ** -16 + 1e-30).all())

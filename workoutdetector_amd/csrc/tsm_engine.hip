@@ -90,6 +90,26 @@ void to_split(std::vector<float> *v) {
   }
 }
 
+// Stem weights for the bf16 formats, whose input is stored as pixel pairs (tsm_kernels.hip, pack_input_kernel):
+// K = (ky, pair j, pixel-in-pair q, c4) = 7 x 4 x 2 x 4 = 224, covering pixels 2ox-4 .. 2ox+3, i.e. kx = 2j + q - 1
+// (kx = -1 and c = 3 carry zero weights).
+void fold_and_pack_stem_pairs(const float *w, const float *gamma, const float *beta, const float *mean,
+                              const float *var, int cout, int kp, std::vector<float> *wp, std::vector<float> *bias) {
+  wp->assign((size_t)cout * kp, 0.f);
+  bias->resize(cout);
+  for (int o = 0; o < cout; ++o) {
+    const float scale = gamma[o] / std::sqrt(var[o] + kBnEps);
+    (*bias)[o] = beta[o] - mean[o] * scale;
+    float *dst = wp->data() + (size_t)o * kp;
+    for (int c = 0; c < 3; ++c)
+      for (int ky = 0; ky < 7; ++ky)
+        for (int kx = 0; kx < 7; ++kx) {
+          const int j = (kx + 1) >> 1, q = (kx + 1) & 1;
+          dst[((ky * 4 + j) * 2 + q) * 4 + c] = w[(((size_t)o * 3 + c) * 7 + ky) * 7 + kx] * scale;
+        }
+  }
+}
+
 // Fold BN into the conv and pack OIHW -> [Cout][Kp], K = (ky, kx, c) with c padded to cp.
 void fold_and_pack(const float *w, const float *gamma, const float *beta, const float *mean,
                    const float *var, int cout, int cin, int k, int cp, int kp, std::vector<float> *wp,
@@ -167,8 +187,9 @@ void build_topology(tsm_engine *e) {
   stem.wkey = "base_model.conv1.weight";
   stem.bnp = "base_model.bn1";
   stem.cin = 3; stem.cout = 64; stem.k = 7; stem.stride = 2;
-  stem.cp = e->prec == tsm::kPrecF32 ? 4 : 8;  // the bf16 formats work on 8-channel groups
-  stem.kp = round_up(7 * 7 * stem.cp, e->prec == tsm::kPrecBf16 ? 64 : 32);
+  stem.cp = 4;
+  // fp32: K = 49 taps x 4 channels; bf16 formats: K = 7 rows x 4 pixel pairs x 8 (fold_and_pack_stem_pairs)
+  stem.kp = e->prec == tsm::kPrecF32 ? round_up(7 * 7 * 4, 32) : round_up(7 * 4 * 8, e->prec == tsm::kPrecBf16 ? 64 : 32);
   e->convs.push_back(stem);
   int cin = 64;
   for (int li = 0; li < 4; ++li) {
@@ -389,7 +410,8 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     TSM_LAUNCH(e, s, tsm::launch_pack_input(d_clips, e->d_in4, n, cfg.height, cfg.width,
                                             layout == TSM_LAYOUT_NTCHW ? 1 : 0, prec, s));
   }
-  if (want("input")) return hit(in4, n, cfg.height, cfg.width, e->convs[0].cp);
+  if (want("input"))  // fp32: [n,H,W,4]; bf16 formats: pixel pairs [n,H,ceil(W/2),8]
+    return prec == tsm::kPrecF32 ? hit(in4, n, cfg.height, cfg.width, 4) : hit(in4, n, cfg.height, (cfg.width + 1) / 2, 8);
 
   float *cur = e->buf[0], *out = e->buf[1], *t1 = e->buf[2], *t2 = e->buf[3], *idb = e->buf[4];
   {
@@ -579,8 +601,12 @@ int tsm_finalize(tsm_engine *e) {
     for (const HostTensor *t : {g, b, m, v})
       if (t->shape.size() != 1 || t->shape[0] != c.cout) return fail(e, TSM_ERR_SHAPE, "BN shape mismatch for " + c.bnp);
     std::vector<float> wp, bias;
-    fold_and_pack(w->data.data(), g->data.data(), b->data.data(), m->data.data(), v->data.data(), c.cout,
-                  c.cin, c.k, c.cp, c.kp, &wp, &bias);
+    if (c.k == 7 && e->prec != tsm::kPrecF32)
+      fold_and_pack_stem_pairs(w->data.data(), g->data.data(), b->data.data(), m->data.data(), v->data.data(), c.cout,
+                               c.kp, &wp, &bias);
+    else
+      fold_and_pack(w->data.data(), g->data.data(), b->data.data(), m->data.data(), v->data.data(), c.cout,
+                    c.cin, c.k, c.cp, c.kp, &wp, &bias);
     if (c.k == 1) {  // fp32 packed copies of the 1x1 layers, for the conv3 + downsample fusion below
       host_wp[ci] = wp;
       host_bias[ci] = bias;
@@ -644,7 +670,7 @@ int tsm_finalize(tsm_engine *e) {
   }
   rc = dev_alloc(e, &e->d_in, frames * 3 * cfg.height * cfg.width);
   if (rc) return rc;
-  rc = dev_alloc(e, &e->d_in4, frames * 8 * cfg.height * cfg.width);
+  rc = dev_alloc(e, &e->d_in4, frames * 4 * cfg.height * (cfg.width + 1));  // 16 bytes per pixel in every format (pairs: odd widths padded)
   if (rc) return rc;
   rc = dev_alloc(e, &e->d_pooled, frames * 2048);
   if (rc) return rc;
@@ -823,8 +849,9 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
   hipStream_t s = static_cast<hipStream_t>(stream);
   ConvLayer c;
   c.cin = cin; c.cout = cout; c.k = k; c.stride = stride;
-  c.cp = stem ? (x3 ? 8 : 4) : cin;
-  c.kp = round_up(k * k * c.cp, prec == tsm::kPrecBf16 ? 64 : 32);
+  c.cp = stem ? 4 : cin;
+  c.kp = (stem && x3) ? round_up(7 * 4 * 8, prec == tsm::kPrecBf16 ? 64 : 32)
+                      : round_up(k * k * c.cp, prec == tsm::kPrecBf16 ? 64 : 32);
   std::vector<float> hw_((size_t)cout * cin * k * k), hg(cout), hb(cout), hm(cout), hv(cout), wp, bias;
 #define TSM_HIP0(call)                                                                              \
   do {                                                                                              \
@@ -837,7 +864,12 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
   TSM_HIP0(hipMemcpy(hb.data(), beta, cout * sizeof(float), hipMemcpyDeviceToHost));
   TSM_HIP0(hipMemcpy(hm.data(), mean, cout * sizeof(float), hipMemcpyDeviceToHost));
   TSM_HIP0(hipMemcpy(hv.data(), var, cout * sizeof(float), hipMemcpyDeviceToHost));
-  fold_and_pack(hw_.data(), hg.data(), hb.data(), hm.data(), hv.data(), cout, cin, k, c.cp, c.kp, &wp, &bias);
+  if (stem && x3) {
+    if (stride != 2) return fail(nullptr, TSM_ERR_UNSUPPORTED, "the bf16 formats implement the 7x7 stem for stride 2 only");
+    fold_and_pack_stem_pairs(hw_.data(), hg.data(), hb.data(), hm.data(), hv.data(), cout, c.kp, &wp, &bias);
+  } else {
+    fold_and_pack(hw_.data(), hg.data(), hb.data(), hm.data(), hv.data(), cout, cin, k, c.cp, c.kp, &wp, &bias);
+  }
   if (prec == tsm::kPrecBf16x3) to_split(&wp);
   if (prec == tsm::kPrecBf16) to_bf16(&wp);
   float *d_w = nullptr, *d_b = nullptr, *d_x4 = nullptr, *d_xs = nullptr, *d_rs = nullptr, *d_ys = nullptr;

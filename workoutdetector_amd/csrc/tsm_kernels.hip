@@ -142,7 +142,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
   const int HoWo = p.Ho * p.Wo;
   const int n_first = m0 / HoWo;
   const int frame0 = SHIFT ? (n_first > 0 ? n_first - 1 : 0) : n_first;
-  const size_t frame_elems = (size_t)p.Hi * p.Wi * p.C;
+  // bf16-format stem: the input is stored as pixel PAIRS (8-element groups = 2 pixels x 4 channels, odd
+  // widths padded with a zero pixel), so a frame is Hi x ceil(Wi/2) groups.
+  constexpr bool PAIRS = KS == 7 && PREC != kPrecF32;
+  const int wpairs = (p.Wi + 1) >> 1;
+  const size_t frame_elems = PAIRS ? (size_t)p.Hi * wpairs * 8 : (size_t)p.Hi * p.Wi * p.C;
   const size_t a_bytes = ((size_t)p.N - frame0) * frame_elems * EB;
   const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)frame0 * frame_elems * EB), 0,
@@ -180,7 +184,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
     if (KS == 7) {
       a_off[pp] = ok ? (unsigned)((n - frame0) * frame_bytes) : kInvalid;
       a_iy[pp] = iy0;
-      a_ix[pp] = ix0;
+      // PAIRS: the 7 taps of a row (pixels 2ox-3 .. 2ox+3) sit in the 4 aligned pixel pairs starting at
+      // pair ox-2 (pixel 2ox-4, whose weight is zero)
+      a_ix[pp] = PAIRS ? (ix0 - 1) >> 1 : ix0;
     } else {
       const int base = (n - frame0) * frame_bytes + (iy0 * p.Wi + ix0) * p.C * EB + chunk * 16;
       a_off[pp] = (KS == 1 && !ok) ? kInvalid : (unsigned)base;
@@ -265,14 +271,24 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
       } else if (KS == 3) {
         ra[pp] = buf_load4(rsrcA, (((a_mask[pp] >> k.tap) & 1u) ? a_off[pp] + (unsigned)k.tap_off : kInvalid) | k.dead, 0);
       } else {
-        // stem: fp32 C = 4 -> one tap per 16-B chunk; split C = 8 -> one tap per chunk pair (hi, lo);
-        // taps >= 49 are K padding
-        const int tap = X3 ? (kt * 8 + chunk) >> 1 : kt * 8 + chunk;
-        const int ky = tap / 7, kx = tap - ky * 7;
-        const int iy = a_iy[pp] + ky, ix = a_ix[pp] + kx;
-        const bool ok = tap < 49 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        const unsigned pix = X3 ? (unsigned)((iy * p.Wi + ix) * 32 + (chunk & 1) * 16) : (unsigned)((iy * p.Wi + ix) * 16);
-        ra[pp] = buf_load4(rsrcA, (ok ? a_off[pp] + pix : kInvalid) | k.dead, 0);
+        if constexpr (PAIRS) {
+          // bf16-format stem: K = (ky, pair j, pixel-in-pair, c4) = 7 x 4 x 8 = 224; one 8-element group
+          // per 16-B chunk (bf16) or per chunk pair hi/lo (split); groups >= 28 are K padding
+          const int g = X3 ? (kt * 8 + chunk) >> 1 : kt * 8 + chunk;
+          const int ky = g >> 2, j = g & 3;
+          const int iy = a_iy[pp] + ky, pc = a_ix[pp] + j;
+          const bool ok = g < 28 && (unsigned)iy < (unsigned)p.Hi && (unsigned)pc < (unsigned)wpairs;
+          const unsigned pix = X3 ? (unsigned)((iy * wpairs + pc) * 32 + (chunk & 1) * 16)
+                                  : (unsigned)((iy * wpairs + pc) * 16);
+          ra[pp] = buf_load4(rsrcA, (ok ? a_off[pp] + pix : kInvalid) | k.dead, 0);
+        } else {
+          // fp32 stem: C = 4 -> one tap per 16-B chunk; taps >= 49 are K padding
+          const int tap = kt * 8 + chunk;
+          const int ky = tap / 7, kx = tap - ky * 7;
+          const int iy = a_iy[pp] + ky, ix = a_ix[pp] + kx;
+          const bool ok = tap < 49 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+          ra[pp] = buf_load4(rsrcA, (ok ? a_off[pp] + (unsigned)((iy * p.Wi + ix) * 16) : kInvalid) | k.dead, 0);
+        }
       }
     } else {
       const int pp = item - APASS;
@@ -839,7 +855,9 @@ hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
   if (p.x2 && (ks != 1 || p.T > 0 || p.res || p.K1 % kc != 0 || p.C2 % kc != 0 || p.K1 + p.C2 != p.Kp || p.K1 != p.C))
     return hipErrorInvalidValue;
   if (p.prec != kPrecF32 && p.prec != kPrecBf16x3 && p.prec != kPrecBf16) return hipErrorInvalidValue;
-  if (p.prec != kPrecF32 && ((p.T > 0 && p.fold % 8 != 0) || (ks == 7 && p.C != 8))) return hipErrorInvalidValue;
+  if (p.prec != kPrecF32 && p.T > 0 && p.fold % 8 != 0) return hipErrorInvalidValue;
+  // stem: 4 channels per pixel (3 + a zero); the bf16 formats read pixel pairs, which needs stride 2 / pad 3
+  if (ks == 7 && (p.C != 4 || (p.prec != kPrecF32 && (p.stride != 2 || p.pad != 3)))) return hipErrorInvalidValue;
   // 32-bit byte offsets inside a workgroup's rebased window: a tile touches at most
   // BM/(Ho*Wo) + 4 input frames.
   const double frames = 128.0 / ((double)p.Ho * p.Wo) + 4.0;
@@ -926,27 +944,41 @@ static unsigned grid_for(int64_t total, int cap) {
   } while (0)
 
 // ---------------------------------------------------------------------------------------------
-// pack_input: [N,3,H,W] or [N,H,W,3] fp32 -> one group per pixel (NHWC4 fp32 / NHWC8 split / NHWC8 bf16,
-// padding channels zero) so every stem tap is whole 16-byte chunks.  One thread per pixel.
+// pack_input: [N,3,H,W] or [N,H,W,3] fp32 -> the stem's input format, padding channels zero:
+//   fp32   one 4-channel group per pixel (NHWC4)
+//   bf16 formats   one 8-element group per pixel PAIR: (pixel 2j: c0 c1 c2 0, pixel 2j+1: c0 c1 c2 0), rows of
+//                  ceil(W/2) pairs (an odd width ends in a zero pixel, which is what the conv's padding reads anyway)
+// One thread per group.
 // ---------------------------------------------------------------------------------------------
 template <int FMT>
 __global__ void __launch_bounds__(256) pack_input_kernel(const float *__restrict__ src,
-                                                         float *__restrict__ dst, int64_t n_pix_total,
-                                                         int64_t hw, int nchw) {
+                                                         float *__restrict__ dst, int64_t n_groups, int h, int w,
+                                                         int nchw) {
+  constexpr int PX = FMT == kPrecF32 ? 1 : 2;  // pixels per group
+  const int wg = (w + PX - 1) / PX;
+  const int64_t hw = (int64_t)h * w;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix_total; i += stride) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_groups; i += stride) {
+    const int gx = (int)(i % wg);
+    const int64_t row = i / wg;  // n * h + y
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (nchw) {
-      const int64_t n = i / hw, pix = i - n * hw;
-      const float *b = src + n * 3 * hw + pix;
-      v[0] = b[0];
-      v[1] = b[hw];
-      v[2] = b[2 * hw];
-    } else {
-      const float *b = src + i * 3;
-      v[0] = b[0];
-      v[1] = b[1];
-      v[2] = b[2];
+#pragma unroll
+    for (int q = 0; q < PX; ++q) {
+      const int x = gx * PX + q;
+      if (x < w) {
+        if (nchw) {
+          const int64_t n = row / h, y = row - n * h;
+          const float *b = src + n * 3 * hw + y * w + x;
+          v[4 * q + 0] = b[0];
+          v[4 * q + 1] = b[hw];
+          v[4 * q + 2] = b[2 * hw];
+        } else {
+          const float *b = src + (row * w + x) * 3;
+          v[4 * q + 0] = b[0];
+          v[4 * q + 1] = b[1];
+          v[4 * q + 2] = b[2];
+        }
+      }
     }
     store_group<FMT>(dst + i * Fmt<FMT>::gf, v);
   }
@@ -954,8 +986,9 @@ __global__ void __launch_bounds__(256) pack_input_kernel(const float *__restrict
 
 hipError_t launch_pack_input(const float *src, float *dst, int64_t n_frames, int h, int w, int nchw, int prec,
                              hipStream_t s) {
-  const int64_t hw = (int64_t)h * w, total = n_frames * hw;
-  TSM_DISPATCH_FMT(prec, pack_input_kernel, grid_for(total, 4096), s, src, dst, total, hw, nchw);
+  const int wg = prec == kPrecF32 ? w : (w + 1) / 2;
+  const int64_t total = n_frames * h * wg;
+  TSM_DISPATCH_FMT(prec, pack_input_kernel, grid_for(total, 4096), s, src, dst, total, h, w, nchw);
   return hipGetLastError();
 }
 
@@ -1007,35 +1040,45 @@ hipError_t launch_to_f32(const float *x, float *y, int64_t n8, int prec, hipStre
 // datasets/build.py:131-136 of the reference (torchvision tensor transforms).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) preprocess_kernel(const PreprocParams p) {
-  const int64_t total = (int64_t)p.n * p.crop * p.crop;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+__device__ __forceinline__ void preprocess_pixel(const PreprocParams &p, const T *frame, int cy, int cx, float *v) {
   const float sh = (float)p.h / (float)p.nh, sw = (float)p.w / (float)p.nw;
   const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  float fy = sh * ((float)(cy + p.top) + 0.5f) - 0.5f;
+  float fx = sw * ((float)(cx + p.left) + 0.5f) - 0.5f;
+  fy = fy < 0.f ? 0.f : fy;
+  fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+  const float h1 = fy - (float)y0, h0 = 1.f - h1, w1 = fx - (float)x0, w0 = 1.f - w1;
+  const T *r0 = frame + (int64_t)y0 * p.w * 3, *r1 = frame + (int64_t)y1 * p.w * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float p00 = (float)r0[x0 * 3 + c], p01 = (float)r0[x1 * 3 + c];
+    const float p10 = (float)r1[x0 * 3 + c], p11 = (float)r1[x1 * 3 + c];
+    const float t = h0 * (w0 * p00 + w1 * p01) + h1 * (w0 * p10 + w1 * p11);
+    v[c] = (t * p.pre_scale - mean[c]) / stdv[c];
+  }
+}
+
+// One thread per output group: a pixel (out_mode 0 NHWC4 fp32, 1 NCHW fp32) or a pixel pair (2 split-bf16,
+// 3 bf16: the stem's packed-pair input, see pack_input_kernel).
+template <typename T>
+__global__ void __launch_bounds__(256) preprocess_kernel(const PreprocParams p) {
+  const int px = p.out_mode >= 2 ? 2 : 1;
+  const int wg = (p.crop + px - 1) / px;
+  const int64_t total = (int64_t)p.n * p.crop * wg;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const T *src = static_cast<const T *>(p.src);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int cx = (int)(i % p.crop);
-    const int cy = (int)((i / p.crop) % p.crop);
-    const int64_t f = i / ((int64_t)p.crop * p.crop);
-    float fy = sh * ((float)(cy + p.top) + 0.5f) - 0.5f;
-    float fx = sw * ((float)(cx + p.left) + 0.5f) - 0.5f;
-    fy = fy < 0.f ? 0.f : fy;
-    fx = fx < 0.f ? 0.f : fx;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
-    const float h1 = fy - (float)y0, h0 = 1.f - h1, w1 = fx - (float)x0, w0 = 1.f - w1;
-    const T *b = src + f * (int64_t)p.h * p.w * 3;
-    const T *r0 = b + (int64_t)y0 * p.w * 3, *r1 = b + (int64_t)y1 * p.w * 3;
+    const int gx = (int)(i % wg);
+    const int cy = (int)((i / wg) % p.crop);
+    const int64_t f = i / ((int64_t)wg * p.crop);
+    const T *frame = src + f * (int64_t)p.h * p.w * 3;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float p00 = (float)r0[x0 * 3 + c], p01 = (float)r0[x1 * 3 + c];
-      const float p10 = (float)r1[x0 * 3 + c], p11 = (float)r1[x1 * 3 + c];
-      const float t = h0 * (w0 * p00 + w1 * p01) + h1 * (w0 * p10 + w1 * p11);
-      v[c] = (t * p.pre_scale - mean[c]) / stdv[c];
-    }
+    preprocess_pixel<T>(p, frame, cy, gx * px, v);
+    if (px == 2 && gx * 2 + 1 < p.crop) preprocess_pixel<T>(p, frame, cy, gx * 2 + 1, v + 4);
     if (p.out_mode == 1) {
-      float *o = p.dst + f * 3 * (int64_t)p.crop * p.crop + (int64_t)cy * p.crop + cx;
+      float *o = p.dst + f * 3 * (int64_t)p.crop * p.crop + (int64_t)cy * p.crop + gx;
       o[0] = v[0];
       o[(int64_t)p.crop * p.crop] = v[1];
       o[2 * (int64_t)p.crop * p.crop] = v[2];
@@ -1053,7 +1096,8 @@ hipError_t launch_preprocess(const PreprocParams &p, hipStream_t s) {
   if (p.n <= 0 || p.h <= 0 || p.w <= 0 || p.crop <= 0 || p.top < 0 || p.left < 0 || p.top + p.crop > p.nh ||
       p.left + p.crop > p.nw)
     return hipErrorInvalidValue;
-  const int64_t total = (int64_t)p.n * p.crop * p.crop;
+  const int px = p.out_mode >= 2 ? 2 : 1;
+  const int64_t total = (int64_t)p.n * p.crop * ((p.crop + px - 1) / px);
   const unsigned grid = grid_for(total, 8192);
   if (p.src_is_u8)
     hipLaunchKernelGGL(preprocess_kernel<unsigned char>, dim3(grid), dim3(256), 0, s, p);

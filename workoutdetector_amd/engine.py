@@ -318,7 +318,8 @@ def preprocess_frames(frames, resize: int = 256, crop: int = 224, scale_255: boo
     """HIP test transform.  frames: CUDA uint8 or float32 [n,H,W,3] (decoder layout, values 0..255).
     Returns float32 [n,crop,crop,4] (``packed``: feed ``forward_device(..., layout=LAYOUT_NTHWC4)``),
     [n,3,crop,crop] (``packed=False``), or with ``layout=engine.packed_layout`` the packed format of that
-    engine (LAYOUT_NTHWC8S for a bf16x3 engine: a float32-typed buffer [n,crop,crop,8] holding split-bf16)."""
+    engine (LAYOUT_NTHWC8S for a bf16x3 engine: a float32-typed buffer [n,crop,ceil(crop/2),8] holding one
+    split-bf16 group per pixel pair; LAYOUT_NTHWC8B: [n,crop,ceil(crop/2),4] float slots = 8 bf16 per pair)."""
     import torch
     frames = frames.contiguous()
     if frames.dtype == torch.uint8:
@@ -332,8 +333,9 @@ def preprocess_frames(frames, resize: int = 256, crop: int = 224, scale_255: boo
         raise ValueError('frames must be a CUDA tensor [n,H,W,3]')
     if layout is None:
         layout = _lib.LAYOUT_NTHWC4 if packed else _lib.LAYOUT_NTCHW
-    shape = {_lib.LAYOUT_NTHWC4: (n, crop, crop, 4), _lib.LAYOUT_NTHWC8S: (n, crop, crop, 8),
-             _lib.LAYOUT_NTHWC8B: (n, crop, crop, 4),      # 8 bf16 = 16 bytes = 4 float slots per pixel
+    pairs = (crop + 1) // 2     # the bf16 formats store pixel PAIRS: one 8-element group = 2 pixels x 4 channels
+    shape = {_lib.LAYOUT_NTHWC4: (n, crop, crop, 4), _lib.LAYOUT_NTHWC8S: (n, crop, pairs, 8),
+             _lib.LAYOUT_NTHWC8B: (n, crop, pairs, 4),     # 8 bf16 = 16 bytes = 4 float slots per pair
              _lib.LAYOUT_NTCHW: (n, 3, crop, crop)}[layout]
     out = torch.empty(shape, dtype=torch.float32, device=frames.device)
     _lib.check(_lib.load().tsm_preprocess(frames.data_ptr(), pixel, n, h, w, out.data_ptr(), layout, resize, crop,
