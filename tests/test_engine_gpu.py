@@ -141,8 +141,8 @@ def test_autotuned_tiles_are_bitwise_invariant(hip_lib, sd0, monkeypatch):
 
 
 def test_create_model_from_checkpoint_and_onnx(hip_lib, sd0, tmp_path):
-    """The three weight sources give the same logits: state dict, torch checkpoint with 'module.' keys
-    (create_model's remap, tsm.py:451-473) and a BN-folded .onnx export (onnx_import)."""
+    """The four weight sources give the same logits: state dict, torch checkpoint with 'module.' keys
+    (create_model's remap, tsm.py:451-473), an mmaction2-style checkpoint and a BN-folded .onnx export."""
     from tests._onnx_writer import write_model
     from tests.test_onnx_import import _folded_export
     from workoutdetector_amd.engine import TsmEngine, create_model
@@ -154,6 +154,12 @@ def test_create_model_from_checkpoint_and_onnx(hip_lib, sd0, tmp_path):
     ck = {'state_dict': {('module.' + k).replace('module.fc.', 'module.new_fc.'): sd0[k] for k in keys}}
     torch.save(ck, tmp_path / 'tsm.pth')
     m = create_model(num_class=12, checkpoint=str(tmp_path / 'tsm.pth'), device='cuda:0', height=64, width=64, max_clips=1)
+    assert np.array_equal(m.run(None, {'input': x})[0], want)
+    m.close()
+    from tests.test_weights import _to_mmaction          # mmaction2 checkpoint of the reference's --mmlab branch
+    torch.save({'meta': {}, 'state_dict': _to_mmaction(sd0)}, tmp_path / 'tsm_mmaction.pth')
+    m = create_model(num_class=12, checkpoint=str(tmp_path / 'tsm_mmaction.pth'), device='cuda:0', height=64, width=64,
+                     max_clips=1)
     assert np.array_equal(m.run(None, {'input': x})[0], want)
     m.close()
     nodes, inits = _folded_export({k: v.numpy() for k, v in sd0.items()})

@@ -29,3 +29,38 @@ def test_remap_checkpoint_keys_like_create_model():
     assert 'fc.weight' in out and 'fc.bias' in out and 'new_fc.weight' not in out
     out = remap_checkpoint_keys(ck, num_class=174)       # pretrained head of another size is dropped
     assert 'fc.weight' not in out and 'new_fc.weight' not in out
+
+
+def _to_mmaction(sd):
+    """Inverse mapping, written independently: engine keys -> mmaction2 ResNetTSM / TSMHead names."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith('fc.'):
+            out['cls_head.fc_cls.' + k[3:]] = v
+            continue
+        p = k.split('.')[1:]
+        if p[0] == 'conv1':
+            out['backbone.conv1.conv.' + '.'.join(p[1:])] = v
+        elif p[0] == 'bn1':
+            out['backbone.conv1.bn.' + '.'.join(p[1:])] = v
+        elif p[2] == 'downsample':
+            out[f'backbone.{p[0]}.{p[1]}.downsample.{"conv" if p[3] == "0" else "bn"}.' + '.'.join(p[4:])] = v
+        elif p[2].startswith('conv'):
+            out[f'backbone.{p[0]}.{p[1]}.{p[2]}.conv.' + '.'.join(p[3:])] = v
+        else:                                            # bnN of a block lives inside convN's ConvModule
+            out[f'backbone.{p[0]}.{p[1]}.conv{p[2][-1]}.bn.' + '.'.join(p[3:])] = v
+    return out
+
+
+def test_remap_mmaction_keys_round_trip():
+    """mmaction2 checkpoints of the reference's --mmlab branch (backbone.* ConvModules, cls_head.fc_cls)."""
+    from workoutdetector_amd.weights import is_mmaction_state_dict, remap_mmaction_keys
+    sd = make_state_dict(3, 12)
+    mm = _to_mmaction(sd)
+    mm['backbone.conv1.bn.num_batches_tracked'] = np.zeros((), np.int64)
+    assert 'backbone.layer2.0.conv1.conv.net.weight' in mm and 'backbone.layer2.0.downsample.bn.running_var' in mm
+    assert is_mmaction_state_dict(mm) and not is_mmaction_state_dict(sd)
+    back = remap_mmaction_keys(mm)
+    tracked = back.pop('base_model.bn1.num_batches_tracked')
+    assert tracked.shape == () and set(back) == set(sd)
+    assert all(np.array_equal(back[k], sd[k]) for k in sd)

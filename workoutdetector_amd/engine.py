@@ -22,7 +22,7 @@ from typing import Dict, List, Mapping, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from .weights import make_state_dict, remap_checkpoint_keys
+from .weights import is_mmaction_state_dict, make_state_dict, remap_checkpoint_keys, remap_mmaction_keys
 
 
 @dataclass
@@ -241,7 +241,8 @@ def create_model(num_class: int = 2, num_segments: int = 8, base_model: str = 'r
                  **kwargs) -> TsmEngine:
     """Counterpart of the reference factory (tsm.py:422-476) returning a ready TsmEngine.
 
-    ``checkpoint`` is a ``torch.save``d dict with a ``state_dict`` entry; its keys are remapped like
+    ``checkpoint`` is a ``torch.save``d dict with a ``state_dict`` entry (mmaction2 ``backbone.*``/``cls_head.*``
+    checkpoints of the reference's --mmlab branch are recognised and mapped by ``weights.remap_mmaction_keys``); its keys are remapped like
     the reference does (strip the first dotted component, last two entries are the classifier).  A path
     ending in ``.onnx`` (the reference's exported model, scripts/export_model.py:35-47) is read by
     ``onnx_import.load_onnx_state_dict``.
@@ -266,7 +267,9 @@ def create_model(num_class: int = 2, num_segments: int = 8, base_model: str = 'r
     elif checkpoint is not None:
         import torch
         ckpt = torch.load(checkpoint, map_location='cpu')
-        sd = remap_checkpoint_keys(ckpt['state_dict'], num_class)
+        raw = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
+        # mmaction2 checkpoints (the reference's --mmlab branch) vs the reference's own TSM / Lightning ones
+        sd = remap_mmaction_keys(raw) if is_mmaction_state_dict(raw) else remap_checkpoint_keys(raw, num_class)
     else:
         sd = make_state_dict(seed=seed, num_class=num_class)
     return TsmEngine(num_class=num_class, num_segments=num_segments, height=height, width=width,

@@ -82,6 +82,45 @@ def remap_checkpoint_keys(state_dict: Mapping[str, object], num_class: int) -> '
     return OrderedDict(('.'.join(k.split('.')[1:]), v) for k, v in items.items())
 
 
+def is_mmaction_state_dict(state_dict: Mapping[str, object]) -> bool:
+    """mmaction2 ``Recognizer2D`` checkpoints (the reference's ``--mmlab`` branch, utils/inference_count.py:516-519,
+    configs/tsm_MultiActionRepCount_sthv2.py:5-22) name their parts ``backbone.*`` / ``cls_head.*``."""
+    return any(k.startswith('backbone.') for k in state_dict) and any(k.startswith('cls_head.') for k in state_dict)
+
+
+def remap_mmaction_keys(state_dict: Mapping[str, object]) -> 'OrderedDict[str, object]':
+    """mmaction2 0.24 ``ResNetTSM`` + ``TSMHead`` keys -> engine keys.
+
+    mmaction builds every conv as a ``ConvModule`` (``.conv`` + ``.bn``) and wraps ``conv1.conv`` of each block in
+    ``TemporalShift`` (``.net``): ``backbone.layer1.0.conv1.conv.net.weight`` -> ``base_model.layer1.0.conv1.net.weight``,
+    ``backbone.layer1.0.conv1.bn.*`` -> ``base_model.layer1.0.bn1.*``, ``downsample.conv/bn`` -> ``downsample.0/1``,
+    stem ``backbone.conv1.conv/bn`` -> ``base_model.conv1`` / ``base_model.bn1``, ``cls_head.fc_cls`` -> ``fc``.
+    Same graph as the reference's own TSM (pytorch-style ResNet-50: stride on the 3x3; blockres shift, shift_div 8)."""
+    out: 'OrderedDict[str, object]' = OrderedDict()
+    for k, v in state_dict.items():
+        if k.startswith('cls_head.fc_cls.'):
+            out['fc.' + k[len('cls_head.fc_cls.'):]] = v
+            continue
+        if not k.startswith('backbone.'):
+            continue                                    # e.g. optimizer-side buffers
+        parts = k[len('backbone.'):].split('.')
+        if parts[0] == 'conv1':                         # stem ConvModule
+            tail = parts[2:]
+            name = ['conv1'] + tail if parts[1] == 'conv' else ['bn1'] + tail
+        elif parts[0].startswith('layer'):
+            layer, blk, mod, kind, tail = parts[0], parts[1], parts[2], parts[3], parts[4:]
+            if mod == 'downsample':
+                name = [layer, blk, 'downsample', '0' if kind == 'conv' else '1'] + tail
+            elif kind == 'conv':
+                name = [layer, blk, mod] + tail         # keeps a leading 'net' for the shifted conv1
+            else:
+                name = [layer, blk, 'bn' + mod[-1]] + tail
+        else:
+            continue
+        out['base_model.' + '.'.join(name)] = v
+    return out
+
+
 def required_keys(num_class_known: bool = True) -> Iterable[str]:
     for wkey, bnp, *_ in conv_specs():
         yield wkey
