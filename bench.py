@@ -67,12 +67,12 @@ def measured_traffic(b, t, h, w, kernel):
         d = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
     except (OSError, ValueError):
         return None
-    c = d.get('config', {})
-    if (c.get('clips_per_gpu'), c.get('num_segments'), c.get('height'), c.get('width')) != (b, t, h, w):
-        return None
-    if d.get('kernel') != kernel:
-        return None
-    return d.get('hbm_bytes_per_launch')
+    for e in d.get('entries', []):
+        c = e.get('config', {})
+        if ((c.get('clips_per_gpu'), c.get('num_segments'), c.get('height'), c.get('width')) == (b, t, h, w)
+                and e.get('kernel') == kernel):
+            return e.get('hbm_bytes_per_launch')
+    return None
 
 
 def cpu_baseline(sd_np, t, h, w, budget_s=15.0):

@@ -97,6 +97,16 @@ def test_error_behaviour(hip_lib, sd0, engine224):
         engine224.run(None, {'input': np.zeros((1, 8, 3, 200, 224), np.float32)})
     with pytest.raises(ValueError):
         engine224.run(None, {'wrong': np.zeros((1, 8, 3, 224, 224), np.float32)})
+    # the C ABI takes bare pointers: buffer sizes are checked on the Python side before anything is launched
+    from workoutdetector_amd import _lib
+    with pytest.raises(ValueError):
+        engine224.forward_device(torch.zeros(1, 8, 3, 224, 200, device='cuda'))
+    with pytest.raises(ValueError):
+        engine224.forward_device(torch.zeros(1, 8, 224, 224, 3, device='cuda'), layout=_lib.LAYOUT_NTHWC4)
+    with pytest.raises(ValueError):
+        engine224.forward_device(torch.zeros(1, 8, 3, 224, 224, device='cuda'), out=torch.zeros(2, 12, device='cuda'))
+    with pytest.raises(ValueError):
+        engine224.forward_host(np.zeros((2, 8, 3, 224, 112), np.float32))
     eng = TsmEngine(max_clips=1)
     with pytest.raises(TsmError) as ei:
         eng.forward_host(np.zeros((1, 8, 3, 224, 224), np.float32))

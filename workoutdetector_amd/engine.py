@@ -128,10 +128,26 @@ class TsmEngine:
         return self
 
     # ---- forwards ---------------------------------------------------------------------------------
+    def _floats_per_clip(self, layout: int) -> int:
+        """float32 slots one clip occupies in ``layout`` (the C ABI takes bare pointers: sizes are checked here)."""
+        t, h, w = self.num_segments, self.height, self.width
+        per = {_lib.LAYOUT_NTCHW: 3 * h * w, _lib.LAYOUT_NTHWC: 3 * h * w, _lib.LAYOUT_NTHWC4: 4 * h * w,
+               _lib.LAYOUT_NTHWC8S: 8 * h * ((w + 1) // 2), _lib.LAYOUT_NTHWC8B: 4 * h * ((w + 1) // 2)}
+        if layout not in per:
+            raise ValueError(f'unknown layout {layout}')
+        return t * per[layout]
+
+    def _check_clips(self, n_elems: int, b: int, layout: int) -> None:
+        if b <= 0 or n_elems != b * self._floats_per_clip(layout):
+            raise ValueError(f'clips hold {n_elems} float32 values; layout {layout} needs {self._floats_per_clip(layout)} '
+                             f'per clip x {b} clips (T={self.num_segments}, H={self.height}, W={self.width})')
+
     def forward_host(self, clips: np.ndarray, layout: int = _lib.LAYOUT_NTCHW) -> np.ndarray:
         """clips: float32 [B,T,3,H,W] (or [B,T,H,W,3] with LAYOUT_NTHWC) in host memory."""
         self._need_finalized()
+        clips = _as_f32(clips)
         b = clips.shape[0]
+        self._check_clips(clips.size, b, layout)
         out = np.empty((b, self.num_class), dtype=np.float32)
         for s in range(0, b, self.max_clips):
             chunk = np.ascontiguousarray(clips[s:s + self.max_clips])
@@ -151,8 +167,12 @@ class TsmEngine:
             raise ValueError(f'tensor on cuda:{clips.device.index}, engine on cuda:{self.device}')
         clips = clips.contiguous()
         b = clips.shape[0]
+        self._check_clips(clips.numel(), b, layout)
         if out is None:
             out = torch.empty((b, self.num_class), dtype=torch.float32, device=clips.device)
+        elif not (out.is_cuda and out.device == clips.device and out.dtype == torch.float32 and out.is_contiguous()
+                  and tuple(out.shape) == (b, self.num_class)):
+            raise ValueError(f'out must be a contiguous float32 [{b},{self.num_class}] tensor on {clips.device}')
         stream = torch.cuda.current_stream(clips.device).cuda_stream
         for s in range(0, b, self.max_clips):
             n = min(self.max_clips, b - s)
@@ -164,6 +184,7 @@ class TsmEngine:
         """Activation after ``stage`` as NHWC float32 ndarray (parity tests)."""
         self._need_finalized()
         clips = _as_f32(clips)
+        self._check_clips(clips.size, clips.shape[0], _lib.LAYOUT_NTCHW)
         n = clips.shape[0] * self.num_segments
         cap = n * max(((self.height + 1) // 2) * ((self.width + 1) // 2) * 64, self.height * self.width * 8)
         buf = np.empty(cap, dtype=np.float32)
@@ -287,11 +308,24 @@ def _stream(t) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _need_cuda_f32(**tensors) -> None:
+    """The C ABI takes bare device pointers: refuse anything that is not a float32 CUDA tensor up front."""
+    import torch
+    for name, t in tensors.items():
+        if t is None:
+            continue
+        if not (hasattr(t, 'is_cuda') and t.is_cuda and t.dtype == torch.float32):
+            raise ValueError(f'{name} must be a float32 CUDA tensor')
+
+
 def temporal_shift_nhwc(x, n_segment: int, fold_div: int = 8):
     """x: CUDA float32 [N*T, H, W, C] (NHWC) -> shifted copy (tsm.py:35-50)."""
     import torch
+    _need_cuda_f32(x=x)
     x = x.contiguous()
     n, h, w, c = x.shape
+    if n_segment <= 0 or n % n_segment:
+        raise ValueError(f'{n} frames are not a whole number of {n_segment}-frame clips')
     y = torch.empty_like(x)
     _lib.check(_lib.load().tsm_temporal_shift(x.data_ptr(), y.data_ptr(), n, n_segment, h * w, c, fold_div,
                                               _stream(x)))
@@ -302,12 +336,17 @@ def conv_bn_act_nhwc(x, w, gamma, beta, mean, var, stride: int = 1, relu: bool =
                      shift_segments: int = 0, fold_div: int = 8, dtype: str = 'f32'):
     """x NHWC [n,h,w,cin], w OIHW; returns NHWC [n,ho,wo,cout]."""
     import torch
+    _need_cuda_f32(x=x, w=w, gamma=gamma, beta=beta, mean=mean, var=var, residual=residual)
     x = x.contiguous()
     n, hi, wi, cin = x.shape
-    cout, _, k, _ = w.shape
+    cout, wcin, k, k2 = w.shape
+    if wcin != cin or k != k2 or any(tuple(t.shape) != (cout,) for t in (gamma, beta, mean, var)):
+        raise ValueError(f'w {tuple(w.shape)} / BatchNorm vectors do not match x {tuple(x.shape)}')
     pad = k // 2
     ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
     y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    if residual is not None and tuple(residual.shape) != tuple(y.shape):
+        raise ValueError(f'residual {tuple(residual.shape)} must have the output shape {tuple(y.shape)}')
     res = None if residual is None else residual.contiguous()
     args = [t.contiguous() for t in (w, gamma, beta, mean, var)]
     _lib.check(_lib.load().tsm_conv_bn_act(x.data_ptr(), *[a.data_ptr() for a in args], _ptr(res), y.data_ptr(),
@@ -348,6 +387,7 @@ def preprocess_frames(frames, resize: int = 256, crop: int = 224, scale_255: boo
 
 def maxpool3x3s2_nhwc(x):
     import torch
+    _need_cuda_f32(x=x)
     x = x.contiguous()
     n, hi, wi, c = x.shape
     y = torch.empty((n, (hi - 1) // 2 + 1, (wi - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
@@ -357,8 +397,11 @@ def maxpool3x3s2_nhwc(x):
 
 def head_nhwc(feat, fc_w, fc_b, n_segment: int):
     import torch
+    _need_cuda_f32(feat=feat, fc_w=fc_w, fc_b=fc_b)
     feat = feat.contiguous()
     n, h, w, c = feat.shape
+    if n_segment <= 0 or n % n_segment or tuple(fc_w.shape)[1:] != (c,) or tuple(fc_b.shape) != (fc_w.shape[0],):
+        raise ValueError(f'feat {tuple(feat.shape)}, fc_w {tuple(fc_w.shape)}, fc_b {tuple(fc_b.shape)}, T={n_segment} do not fit')
     b = n // n_segment
     out = torch.empty((b, fc_w.shape[0]), dtype=torch.float32, device=feat.device)
     _lib.check(_lib.load().tsm_head(feat.data_ptr(), fc_w.contiguous().data_ptr(), fc_b.contiguous().data_ptr(),
