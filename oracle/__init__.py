@@ -17,5 +17,7 @@ Parity status (see DESIGN.md "Oracle"):
     /root/reference and from the image): it is restated from the public
     definition.  The reference holds no numeric logits fixture, so *logits*
     parity is "unpinned by the reference"; golden logits under tests/golden/ are
-    this oracle's outputs on seeded inputs.
+    this oracle's outputs on seeded inputs.  The trunk wiring is cross-checked
+    against an independent public ResNet-50 v1.5 (HuggingFace transformers,
+    tests/test_oracle_wiring.py).
 """
