@@ -54,11 +54,35 @@ def config3(eng, reps=5):
         ic.inference_video(eng, win.float(), transform=tf)
         lat.append(time.perf_counter() - t0)
     lat = sorted(lat[2:])
+    # the engine-native streaming path: StreamBatcher (fused HIP transform, windows of all live streams in one batch)
+    from workoutdetector_amd.streaming import StreamBatcher
+    frames = vid.numpy()
+    sb = StreamBatcher(eng, max_batch=32)
+    lat1 = []
+    for w in range(14):                                   # ONE stream: latency from the 8th frame to its state
+        for f in frames[w * 8:w * 8 + 8]:
+            sb.push('solo', f)
+        t0 = time.perf_counter()
+        sb.step()
+        lat1.append(time.perf_counter() - t0)
+    lat1 = sorted(lat1[2:])
+    sb = StreamBatcher(eng, max_batch=32)
+    for s_ in range(32):                                  # 32 live streams, 4 windows each per step
+        for f in frames[s_ * 32:s_ * 32 + 32]:
+            sb.push(s_, f)
+    sync()
+    t0 = time.perf_counter()
+    out = sb.step()
+    t32 = time.perf_counter() - t0
+    n_win = sum(len(v) for v in out.values())
     return {'clips': int(n), 'end_to_end_s_median': float(np.median(ts)), 'clips_per_s': n / float(np.median(ts)),
             'count': int(count), 'stream_window_latency_ms_median': 1e3 * lat[len(lat) // 2],
+            'stream_batcher_one_stream_window_ms_median': 1e3 * lat1[len(lat1) // 2],
+            'stream_batcher_32_streams_windows_per_s': n_win / t32,
             'note': 'end to end = uint8 frames on the host -> H2D -> tsm_preprocess -> tsm_forward (batches of 32) -> '
                     'D2H logits -> softmax/threshold -> pred_to_count; window latency = reference-style '
-                    'inference_video (torch transform + host round trip) at batch 1'}
+                    'inference_video (torch transform + host round trip) at batch 1; stream_batcher_* = '
+                    'workoutdetector_amd.streaming.StreamBatcher: host uint8 frames -> H2D -> tsm_preprocess -> engine -> states'}
 
 
 def config4(eng, total_clips=10021, n_videos=100):

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .counting import RepCounter, scores_to_preds
-from .inference_count import NUM_SEGMENTS, _engine_device
+from .inference_count import NUM_SEGMENTS, _engine_device, _pinned_pool
 from .transform import TestTransform, build_test_transform
 
 
@@ -84,8 +84,9 @@ class StreamBatcher:
         return st.counter.count, list(st.counter.reps)
 
     # ---- compute ------------------------------------------------------------------------------------------
-    def _logits(self, windows: List[np.ndarray]) -> np.ndarray:
-        """[n,8,H,W,3] uint8 windows (possibly of different sizes) -> raw logits [n, num_class]."""
+    def _logits(self, windows: List[np.ndarray]):
+        """[n,8,H,W,3] uint8 windows (possibly of different sizes) -> raw logits [n, num_class]: a CUDA tensor that is
+        still being computed on the HIP path (the caller syncs once per step), an ndarray on the duck-typed CPU path."""
         dev = _engine_device(self.model)
         if dev is not None and hasattr(self.model, 'packed_layout'):
             from .engine import preprocess_frames
@@ -95,7 +96,16 @@ class StreamBatcher:
                 by_shape.setdefault(w.shape, []).append(i)
             clips = None
             for shape, idx in by_shape.items():
-                fr = torch.from_numpy(np.concatenate([windows[i] for i in idx])).to(dev, non_blocking=True)
+                # gather the windows straight into a reusable page-locked buffer (one host copy, DMA-able)
+                flat, slot = _pinned_pool.take(len(idx) * int(np.prod(shape)))
+                stage = flat.view((len(idx) * shape[0],) + tuple(shape[1:]))
+                host = stage.numpy()
+                for j, i in enumerate(idx):
+                    host[j * shape[0]:(j + 1) * shape[0]] = windows[i]
+                fr = stage.to(dev, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+                _pinned_pool.busy[slot] = done
                 pk = preprocess_frames(fr, resize=self.transform.size, crop=self.transform.crop,
                                        scale_255=self.transform.scale_255, layout=layout)
                 pk = pk.view((len(idx), NUM_SEGMENTS) + tuple(pk.shape[1:]))
@@ -105,7 +115,7 @@ class StreamBatcher:
                     if clips is None:
                         clips = torch.empty((len(windows),) + tuple(pk.shape[1:]), dtype=pk.dtype, device=dev)
                     clips[torch.tensor(idx, device=dev)] = pk
-            return self.model.forward_device(clips.contiguous(), layout=layout).cpu().numpy()
+            return self.model.forward_device(clips.contiguous(), layout=layout)
         xs = [self.transform(torch.from_numpy(w).permute(0, 3, 1, 2).float()) for w in windows]
         name = self.model.get_inputs()[0].name
         return np.asarray(self.model.run(None, {name: torch.stack(xs).numpy()})[0])
@@ -113,6 +123,8 @@ class StreamBatcher:
     def step(self) -> Dict[Hashable, List[Tuple[int, int, int]]]:
         """Run all complete windows (oldest first, round-robin over streams) and update the counters."""
         out: Dict[Hashable, List[Tuple[int, int, int]]] = {}
+        order: List[Hashable] = []
+        pending = []
         while self.ready():
             batch: List[Tuple[Hashable, np.ndarray]] = []
             progressed = True
@@ -122,9 +134,16 @@ class StreamBatcher:
                     if st.windows and len(batch) < self.max_batch:
                         batch.append((sid, st.windows.popleft()))
                         progressed = True
-            logits = self._logits([w for _, w in batch])
+            # enqueue only: the host gathers / pins batch i+1 while the GPU still computes batch i
+            pending.append(self._logits([w for _, w in batch]))
+            order += [sid for sid, _ in batch]
+        if pending:
+            if isinstance(pending[0], torch.Tensor):
+                logits = torch.cat(pending).cpu().numpy()           # the step's only host sync
+            else:
+                logits = np.concatenate(pending)
             states = scores_to_preds(logits.tolist(), threshold=self.threshold, softmax=self.softmax)
-            for (sid, _), state in zip(batch, states):
+            for sid, state in zip(order, states):
                 st = self.streams[sid]
                 widx = len(st.states)
                 st.states.append(state)
