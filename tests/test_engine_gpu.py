@@ -207,3 +207,25 @@ def test_c_program_runs_a_forward(hip_lib, tmp_path):
     out = subprocess.run([exe, 'run'], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'forward ok' in out.stdout
+
+
+@pytest.mark.parametrize('dtype,t,div,h,w,ncls,rtol', [
+    ('f32', 4, 16, 96, 128, 5, 1e-3),        # fold = C/16, non-square, odd class count
+    ('f32', 3, 8, 64, 96, 2, 1e-3),          # odd segment count (the reference's factory default num_class=2)
+    ('f32', 1, 8, 64, 64, 12, 1e-3),         # single-frame clips: both shifted channel groups read zeros
+    ('bf16x3', 4, 8, 96, 64, 7, 1e-3),
+    ('bf16', 2, 8, 64, 64, 12, 5e-2),
+])
+def test_unusual_configurations_against_oracle(hip_lib, dtype, t, div, h, w, ncls, rtol):
+    """Segment counts, shift_div, class counts and aspect ratios other than the headline's, vs the CPU oracle."""
+    from workoutdetector_amd.engine import TsmEngine
+    from workoutdetector_amd.weights import make_state_dict, to_torch
+    sd = make_state_dict(7, ncls)
+    eng = TsmEngine(num_class=ncls, num_segments=t, height=h, width=w, shift_div=div, max_clips=3, state_dict=sd,
+                    dtype=dtype)
+    x = make_input(100 + t, 3, t, h, w)
+    got = eng.run(None, {'input': x})[0]
+    eng.close()
+    want = tsm_oracle.tsm_forward(to_torch(sd), torch.from_numpy(x), n_segment=t, shift_div=div).numpy()
+    assert got.shape == (3, ncls)
+    assert_close(got, want, rtol=rtol, atol_scale=rtol / 10, what=f'{dtype} T={t} div={div} {h}x{w}')
