@@ -87,3 +87,38 @@ def test_sharded_inference_dataset_equals_single_process(tmp_path, golden_dir):
     assert sorted(os.listdir(single)) == sorted(os.listdir(sharded))
     for f in os.listdir(single):
         assert json.load(open(os.path.join(single, f))) == json.load(open(os.path.join(sharded, f)))
+
+
+def _dataset_by_videos_worker(rank, world, root, out_dir):
+    from tests._stub import StubModel
+    from workoutdetector_amd import inference_count as ic
+    ic.inference_dataset(StubModel(), ['test'], out_dir, checkpoint='stub', data_root=root, batch_clips=4, shard='videos')
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_video_sharded_inference_dataset_equals_single_process(tmp_path, golden_dir, world):
+    """shard='videos': whole videos round-robin over the ranks (3 videos over 2 ranks -> a half-empty last round;
+    over 3 ranks -> one round), counts + padded logits all-gathered, rank 0 writes: identical JSON files."""
+    import pandas as pd
+    from tests._stub import StubModel, synthetic_video
+    from workoutdetector_amd import inference_count as ic
+    anno = pd.read_csv(f'{golden_dir}/repcount_annotation.csv', index_col=0)
+    rows = anno[anno['name'].isin(['stu1_40.mp4', 'stu5_32.mp4', 'stu3_53.mp4'])].copy()
+    assert len(rows) == 3
+    rows['name'] = [n.replace('.mp4', '.npy') for n in rows['name']]
+    root = tmp_path / 'RepCount'
+    (root / 'videos' / 'test').mkdir(parents=True)
+    rows.to_csv(root / 'annotation.csv')
+    for i, name in enumerate(rows['name']):
+        np.save(root / 'videos' / 'test' / name, synthetic_video(i, (77, 9, 41)[i], 40 + 2 * i, 30))   # sizes differ
+    single, sharded = str(tmp_path / 'single'), str(tmp_path / 'sharded')
+    ic.inference_dataset(StubModel(), ['test'], single, checkpoint='stub', data_root=str(root))
+    _spawn(_dataset_by_videos_worker, str(root), sharded, world=world)
+    assert sorted(os.listdir(single)) == sorted(os.listdir(sharded)) and len(os.listdir(single)) == 3
+    for f in os.listdir(single):
+        assert json.load(open(os.path.join(single, f))) == json.load(open(os.path.join(sharded, f)))
+    # and the single-process form of the same mode
+    alone = str(tmp_path / 'alone')
+    ic.inference_dataset(StubModel(), ['test'], alone, checkpoint='stub', data_root=str(root), shard='videos')
+    for f in os.listdir(single):
+        assert json.load(open(os.path.join(single, f))) == json.load(open(os.path.join(alone, f)))

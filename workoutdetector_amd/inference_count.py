@@ -20,7 +20,7 @@ What differs from the reference, on purpose:
     that is importable.
   * under ``torch.distributed`` the clips of each video are sharded across ranks in contiguous blocks
     and the per-clip logits are all-gathered once per video (RCCL over xGMI with the nccl backend);
-    rank 0 writes the JSON.
+    rank 0 writes the JSON.  ``shard='videos'`` shards whole videos instead (each decoded once).
   * ``count_by_video_model`` in the reference snapshot is broken (asserts on the missing transform and
     always reads class 0 from an unsorted list, :270,:276,:327); this one implements the documented
     intent: arg-max class of each non-overlapping 8-frame window, softmax + threshold as in
@@ -289,12 +289,63 @@ def scores_dict(logits: torch.Tensor, total_frames: int) -> Dict[int, Dict[int, 
     return {s: {c: float(v) for c, v in enumerate(row)} for s, row in zip(starts, rows)}
 
 
+def _write_score_json(out_dir: str, item, checkpoint: str, logits: torch.Tensor, n_frames: int) -> None:
+    res_dict = dict(video_name=item.video_name, model='video_model', input_shape=[1, 8, 3, 224, 224],
+                    checkpoint=checkpoint, total_frames=n_frames, ground_truth=item.reps, action=item.class_)
+    res_dict['scores'] = scores_dict(logits, n_frames)
+    out_path = os.path.join(out_dir, f'{item.video_name}.score.json')
+    with open(out_path, 'w') as f:
+        json.dump(res_dict, f)
+    print(f'{item.video_name} result saved to {out_path}')
+
+
+def _inference_dataset_by_videos(model, items: list, out_dir: str, checkpoint: str, transform, reader,
+                                 batch_clips: int) -> None:
+    """``shard='videos'``: rank r decodes and runs videos r, r+W, r+2W, ... whole (no video is decoded twice);
+    per round of W videos the ranks exchange [frame count, clip count] and then the padded logits (two small
+    all-gathers), and rank 0 writes the round's JSON files."""
+    rank, world = tdist.world_info()
+    dev = _engine_device(model)
+    on_gpu = dev is not None and world > 1 and torch.distributed.get_backend() == 'nccl'
+    num_class = getattr(model, 'num_class', None)
+    mine = items[rank::world]
+    staged = prefetch_staged(model, ((it, (lambda p=it.video_path: reader(p))) for it in mine))
+    for r0 in range(0, len(items), world):
+        try:
+            item, st = next(staged) if r0 + rank < len(items) else (None, None)
+        except StopIteration:            # cannot happen: `mine` has one entry per round this rank takes part in
+            item, st = None, None
+        if st is not None:
+            local = staged_clip_logits(model, st, transform, batch_clips)
+            meta = torch.tensor([st.total, local.shape[0], local.shape[1]], dtype=torch.int64)
+        else:
+            local = torch.empty((0, num_class or 0), dtype=torch.float32)
+            meta = torch.zeros(3, dtype=torch.int64)
+        if world == 1:
+            _write_score_json(out_dir, item, checkpoint, local, st.total)
+            continue
+        metas = tdist.all_gather_logits((meta.to(dev) if on_gpu else meta).reshape(1, 3)).cpu()
+        per, ncls = int(metas[:, 1].max()), int(metas[:, 2].max())
+        pad = torch.zeros((per, ncls), dtype=torch.float32)
+        pad[:local.shape[0]] = local.reshape(local.shape[0], ncls) if local.numel() else pad[:0]
+        every = tdist.all_gather_logits(pad.to(dev) if on_gpu else pad).cpu().reshape(world, per, ncls)
+        if rank == 0:
+            for r in range(min(world, len(items) - r0)):
+                _write_score_json(out_dir, items[r0 + r], checkpoint, every[r, :int(metas[r, 1])], int(metas[r, 0]))
+
+
 def inference_dataset(model, splits: List[str], out_dir: str, checkpoint: str, person_crop: bool = False,
                       data_root: Optional[str] = None, anno_path: Optional[str] = None,
                       video_reader: Optional[Callable[[str], torch.Tensor]] = None, action: Sequence[str] = ('all',),
-                      batch_clips: int = 32, scale_255: bool = False) -> None:
+                      batch_clips: int = 32, scale_255: bool = False, shard: str = 'clips') -> None:
     """Inference the RepCount dataset; one ``{video_name}.score.json`` per video with the reference's
-    schema: video_name, model, input_shape, checkpoint, total_frames, ground_truth, action, scores."""
+    schema: video_name, model, input_shape, checkpoint, total_frames, ground_truth, action, scores.
+
+    Under ``torch.distributed``: ``shard='clips'`` splits the clips of every video over the ranks (one all-gather per
+    video; lowest latency per video, but every rank reads every video), ``shard='videos'`` gives whole videos to ranks
+    round-robin (each video is decoded once; full-size batches; two small all-gathers per W videos)."""
+    if shard not in ('clips', 'videos'):
+        raise ValueError("shard must be 'clips' or 'videos'")
     rank, _world = tdist.world_info()
     if rank == 0 and not os.path.exists(out_dir):
         os.makedirs(out_dir)
@@ -305,20 +356,16 @@ def inference_dataset(model, splits: List[str], out_dir: str, checkpoint: str, p
     reader = video_reader or read_video
     if rank == 0:
         print('==> transform:', transform)
+    if shard == 'videos':
+        _inference_dataset_by_videos(model, list(data.values()), out_dir, checkpoint, transform, reader, batch_clips)
+        return
     # Video i+1 is read, sliced, pinned and copied to the GPU by a worker thread while video i computes.
     videos = ((item, (lambda p=item.video_path: reader(p))) for item in data.values())
     for item, staged in prefetch_staged(model, videos, lambda v: _rank_clip_range(int(v.shape[0]))):
         n_frames = staged.total
         logits = _gather_video_logits(model, staged_clip_logits(model, staged, transform, batch_clips), n_frames)
-        if rank != 0:
-            continue
-        res_dict = dict(video_name=item.video_name, model='video_model', input_shape=[1, 8, 3, 224, 224],
-                        checkpoint=checkpoint, total_frames=n_frames, ground_truth=item.reps, action=item.class_)
-        res_dict['scores'] = scores_dict(logits, n_frames)
-        out_path = os.path.join(out_dir, f'{item.video_name}.score.json')
-        with open(out_path, 'w') as f:
-            json.dump(res_dict, f)
-        print(f'{item.video_name} result saved to {out_path}')
+        if rank == 0:
+            _write_score_json(out_dir, item, checkpoint, logits, n_frames)
 
 
 def save_scores_to_json(scores: Sequence[Sequence[float]], output_path: str, video_path: str, step: int) -> None:
