@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define TSM_ABI_VERSION 2
+#define TSM_ABI_VERSION 3 /* 3: TSM_LAYOUT_NTHWC8S / 8B hold one group per pixel pair (was: per pixel) */
 
 typedef enum tsm_status {
   TSM_OK = 0,

@@ -8,7 +8,7 @@ from typing import Optional
 
 from .build import LIB_PATH
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MEM_HOST, MEM_DEVICE = 0, 1
 LAYOUT_NTCHW, LAYOUT_NTHWC, LAYOUT_NTHWC4, LAYOUT_NTHWC8S, LAYOUT_NTHWC8B = 0, 1, 2, 3, 4
