@@ -51,6 +51,8 @@ def test_create_rejects_bad_config_before_touching_the_gpu(lib):
     assert lib.tsm_create(ctypes.byref(cfg), ctypes.byref(h)) == -7
     cfg = _lib.TsmConfig(40, 0, 8, 224, 224, 8, 1, 1, 0, 0)
     assert lib.tsm_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    cfg = _lib.TsmConfig(40, 12, 16, 1024, 1024, 8, 1, 1024, 0, 0)   # 2^32 output rows: beyond 32-bit row indices
+    assert lib.tsm_create(ctypes.byref(cfg), ctypes.byref(h)) == -6 and b'2^31' in lib.tsm_last_error(None)
     lib.tsm_destroy(None)                                              # must be a no-op
     assert lib.tsm_forward(None, None, 0, 0, 1, None, None) == -1
 

@@ -511,6 +511,11 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
     return fail(nullptr, TSM_ERR_INVALID_ARG, "num_class, num_segments, max_clips must be positive");
   if (cfg->height < 32 || cfg->width < 32)
     return fail(nullptr, TSM_ERR_INVALID_ARG, "height/width must be >= 32");
+  {  // the conv kernels index output rows (frames x stem output pixels) with 32-bit ints
+    const int64_t rows = (int64_t)cfg->max_clips * cfg->num_segments * ((cfg->height + 1) / 2) * ((cfg->width + 1) / 2);
+    if (rows >= (int64_t)1 << 31)
+      return fail(nullptr, TSM_ERR_CAPACITY, "max_clips * num_segments * (H/2) * (W/2) must stay below 2^31");
+  }
   if (cfg->shift_div <= 0 || (64 % cfg->shift_div) != 0 || (64 / cfg->shift_div) % 4 != 0)
     return fail(nullptr, TSM_ERR_UNSUPPORTED, "shift_div must divide 64 with fold % 4 == 0 (8 or 16... )");
   if (cfg->dtype != TSM_DTYPE_F32 && cfg->dtype != TSM_DTYPE_BF16X3 && cfg->dtype != TSM_DTYPE_BF16)
