@@ -231,7 +231,9 @@ def main():
         prec_id = {'f32': 0, 'bf16x3': 1, 'bf16': 2}[args.dtype]
         main_tile = dom_tile.split('+')[0]
         waves = '1, 1' if main_tile == '32x32' else '4, 2' if main_tile.endswith('w8') else '2, 2'
-        dom_kernel = 'conv_igemm<%s, %s, 3, false, false, %d, false, 1>' % (main_tile.replace('w8', '').replace('x', ', '), waves, prec_id)
+        # template arguments: BM, BN, WGM, WGN, KS, SHIFT, RES, PREC, DUAL, RKT, SEG (fp32 long-K layers accumulate K in segments)
+        dom_kernel = 'conv_igemm<%s, %s, 3, false, false, %d, false, 1, %s>' % (
+            main_tile.replace('w8', '').replace('x', ', '), waves, prec_id, 'true' if args.dtype == 'f32' else 'false')
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         peak_name = ('dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); the kernel executes 3 MFMA FLOPs per algorithmic FLOP'
                      if args.dtype == 'bf16x3' else 'dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)' if args.dtype == 'bf16'

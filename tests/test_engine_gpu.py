@@ -229,3 +229,48 @@ def test_unusual_configurations_against_oracle(hip_lib, dtype, t, div, h, w, ncl
     want = tsm_oracle.tsm_forward(to_torch(sd), torch.from_numpy(x), n_segment=t, shift_div=div).numpy()
     assert got.shape == (3, ncls)
     assert_close(got, want, rtol=rtol, atol_scale=rtol / 10, what=f'{dtype} T={t} div={div} {h}x{w}')
+
+
+def test_split_k_is_bitwise_identical_to_whole_k(hip_lib, sd0, monkeypatch):
+    """Long-K fp32 layers accumulate K in fixed segments (ConvParams::kseg_len), so the split-K launch form (one
+    workgroup per tile and segment + ordered reduction, what the tuner picks at small batch) must reproduce the
+    whole-K form bit for bit, on both tile shapes that implement it and in all three fp32 pipelines."""
+    from workoutdetector_amd.engine import TsmEngine
+    x = make_input(31, 2, 8, 96, 96)
+    outs = {}
+    for name, env in [('whole 64x64', {'TSM_AUTOTUNE': '1', 'TSM_CONV_CODE': '3'}),
+                      ('split 64x64', {'TSM_AUTOTUNE': '1', 'TSM_CONV_CODE': str(0x100 | 3)}),
+                      ('split 32x32', {'TSM_AUTOTUNE': '1', 'TSM_CONV_CODE': str(0x100 | 4)}),
+                      ('split 64x64, two LDS buffers', {'TSM_AUTOTUNE': '1', 'TSM_CONV_CODE': str(0x100 | 3), 'TSM_CONV_RK': '0'}),
+                      ('split 64x64, LDS-DMA', {'TSM_AUTOTUNE': '1', 'TSM_CONV_CODE': str(0x100 | 3), 'TSM_CONV_RK': '2'}),
+                      ('tuned', {})]:
+        for k in ('TSM_AUTOTUNE', 'TSM_CONV_CODE', 'TSM_CONV_RK'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = TsmEngine(height=96, width=96, max_clips=2, state_dict=sd0)
+        outs[name] = eng.run(None, {'input': x})[0]
+        tap = eng.forward_tap(x, 'layer4.1')
+        outs[name + ' tap'] = tap
+        if name == 'tuned':                       # 2 clips of 96x96: layer3/4 have a handful of tiles -> split-K wins
+            tiles = eng.conv_tiles(2)
+            assert any(v.endswith('/splitK') for v in tiles.values()), tiles
+        eng.close()
+    for name in outs:
+        ref = outs['whole 64x64 tap' if name.endswith(' tap') else 'whole 64x64']
+        assert np.array_equal(ref, outs[name]), name
+
+
+def test_cached_split_choice_is_rechecked_against_the_scratch_size(hip_lib, sd0):
+    """Tile choices are cached per power-of-two bucket of the clip count: a split-K choice tuned on 5 clips is reused
+    for 8, where the segment sums of some layer no longer fit the scratch buffer -> that launch must fall back to the
+    whole-K form (same bits), not overrun the buffer."""
+    from workoutdetector_amd.engine import TsmEngine
+    x = make_input(41, 8, 8, 224, 224)
+    eng = TsmEngine(max_clips=8, state_dict=sd0)
+    five = eng.run(None, {'input': x[:5]})[0]          # tunes bucket 8 on 5 clips
+    eight = eng.run(None, {'input': x})[0]
+    assert np.array_equal(five, eight[:5])
+    one = eng.run(None, {'input': x[7:8]})[0]
+    assert np.array_equal(one[0], eight[7])
+    eng.close()

@@ -26,7 +26,7 @@ def last_forward(per, names):
     return [d for d in ids if packs[-2] <= d < packs[-1]]
 
 
-def main(fetch_csv, write_csv, dominant='conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, 1>'):
+def main(fetch_csv, write_csv, dominant='conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, 1, true>'):
     f, fn = load(fetch_csv, 'FETCH_SIZE')
     w, wn = load(write_csv, 'WRITE_SIZE')
     # The two passes are separate processes and the engine's tile autotuner may pick a different shape for

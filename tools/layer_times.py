@@ -27,7 +27,14 @@ def main(path, frames=256, size=224):
     names = [r['Kernel_Name'] for r in rows]
     idx = [i for i, n in enumerate(names) if 'pack_input' in n]
     fw = rows[idx[-2]:idx[-1]]
-    convs = [r for r in fw if 'conv_' in r['Kernel_Name']]
+    # a split-K layer is two launches: the conv and its splitk_reduce, whose time is added to the conv's row
+    convs = []
+    for r in fw:
+        if 'conv_' in r['Kernel_Name']:
+            convs.append(dict(r))
+        elif 'splitk_reduce' in r['Kernel_Name'] and convs:
+            convs[-1]['End_Timestamp'] = int(convs[-1]['End_Timestamp']) + int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+            convs[-1]['Kernel_Name'] = convs[-1]['Kernel_Name'].replace('>', ' +reduce>', 1)
     byname = {r['name']: r for r in layer_table(size, size)}
     order = ['conv1']
     fused = len(convs) == 49          # conv3 + downsample of each stage's first block run as one launch
@@ -51,7 +58,7 @@ def main(path, frames=256, size=224):
         print(f"{nm:22s} {kn:20s} wgs={grid:6d} {dur:8.1f}us {fl / dur / 1e6:7.1f} TF/s  vgpr={r.get('VGPR_Count','?')}")
     span = (int(fw[-1]['End_Timestamp']) - int(fw[0]['Start_Timestamp'])) / 1e3
     print(f'sum conv {tot:.1f} us = {totf / tot / 1e6:.1f} TF/s; forward span {span:.1f} us; '
-          f'other kernels {sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in fw if "conv_" not in r["Kernel_Name"]):.1f} us')
+          f'other kernels {sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in fw if "conv_" not in r["Kernel_Name"] and "splitk_reduce" not in r["Kernel_Name"]):.1f} us')
 
 
 if __name__ == '__main__':

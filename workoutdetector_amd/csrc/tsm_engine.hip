@@ -38,8 +38,20 @@ struct ConvLayer {
   int cin = 0, cout = 0, k = 1, stride = 1;
   int cp = 0;   // channel count the kernel sees (stem: 3 -> 4)
   int kp = 0;   // padded K
+  int kseg = 0; // K-steps per accumulation segment (fp32 layers with long K, ConvParams::kseg_len); 0 = unsegmented
   float *d_w = nullptr, *d_b = nullptr;
 };
+
+// Long-K fp32 layers accumulate K in segments of ~16 K-steps (512 channels-taps) so that they can also run
+// split-K (one workgroup per tile and segment) with bit-identical results when the batch is too small to
+// fill the chip with whole-K tiles.  The choice depends on the layer only, never on the batch size.
+int segment_len(int kp, int prec) {
+  if (prec != tsm::kPrecF32) return 0;
+  const int nk = kp / 32;
+  if (nk < 32) return 0;
+  const int nseg = nk / 16;
+  return (nk + nseg - 1) / nseg;
+}
 
 struct Block {
   int conv1, conv2, conv3, down;  // indices into convs, down = -1 if none
@@ -47,6 +59,7 @@ struct Block {
   // conv3 + downsample as ONE GEMM over K = [conv3 input channels | block input channels]
   float *d_wf = nullptr, *d_bf = nullptr;
   int kpf = 0;
+  int ksegf = 0;  // segment length of the fused GEMM
 };
 
 int ilog2(int v) {
@@ -144,6 +157,8 @@ struct tsm_engine {
   float *d_in4 = nullptr;     // NHWC4 packed input
   float *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float *d_pooled = nullptr, *d_logits = nullptr;
+  float *d_partial = nullptr;   // split-K segment sums [segments][M][Cout] (fp32 engines)
+  size_t partial_elems = 0;
   size_t buf_elems = 0;
   int h1 = 0, w1 = 0, hp = 0, wp = 0;  // stem conv / maxpool output sizes
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -205,6 +220,8 @@ void build_topology(tsm_engine *e) {
       c2.cin = planes; c2.cout = planes; c2.k = 3; c2.stride = stride; c2.cp = planes; c2.kp = 9 * planes;
       ConvLayer c3; c3.wkey = p + ".conv3.weight"; c3.bnp = p + ".bn3";
       c3.cin = planes; c3.cout = planes * 4; c3.k = 1; c3.stride = 1; c3.cp = planes; c3.kp = planes;
+      c1.kseg = segment_len(c1.kp, e->prec);
+      c2.kseg = segment_len(c2.kp, e->prec);
       blk.conv1 = (int)e->convs.size(); e->convs.push_back(c1);
       blk.conv2 = (int)e->convs.size(); e->convs.push_back(c2);
       blk.conv3 = (int)e->convs.size(); e->convs.push_back(c3);
@@ -267,6 +284,7 @@ tsm::ConvParams make_params(const ConvLayer &c, const float *x, const float *res
   p.Wo = (wi + 2 * p.pad - c.k) / c.stride + 1;
   p.Cout = c.cout; p.Kp = c.kp; p.M = n * p.Ho * p.Wo; p.relu = relu ? 1 : 0;
   p.T = T; p.fold = T > 0 ? c.cp / shift_div : 0;
+  p.kseg_len = res ? 0 : c.kseg;   // (no layer with a residual has a long K; the per-op entry point passes kseg = 0)
   return p;
 }
 
@@ -345,9 +363,23 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   // A tile code is `main + 16 * tail`: tail == 0 -> one launch with tile `main`; otherwise the first rows
   // go to `main` tiles (a whole number of full-occupancy rounds) and the rest to `tail` tiles on stream2.
   // Every output element accumulates its K in the same order whatever the tiling, so codes are bit-neutral.
+  // Bit 8 of a code = split-K form of a segmented layer: one workgroup per (tile, K segment) writes raw segment
+  // sums, splitk_reduce adds them in segment order and applies bias / ReLU: bit-identical to the unsplit launch.
   auto launch_code = [&](tsm::ConvParams p, int ks, int code) -> hipError_t {
-    const int main_tile = code & 15, tail_tile = code >> 4;
+    const int main_tile = code & 15, tail_tile = (code >> 4) & 15;
     p.tile = main_tile;
+    // A cached code may come from a smaller batch of the same bucket: the scratch-size condition is re-checked on
+    // EVERY launch (falling back to the whole-K form, which gives the same bits).
+    if ((code & 0x100) && p.kseg_len > 0 &&
+        (size_t)tsm::conv_num_segments(p) * (size_t)p.M * (size_t)p.Cout <= e->partial_elems) {
+      float *y = p.y;
+      p.ksplit = 1;
+      p.y = e->d_partial;
+      hipError_t st = tsm::launch_conv(p, ks, s);
+      if (st == hipSuccess)
+        st = tsm::launch_splitk_reduce(e->d_partial, tsm::conv_num_segments(p), p.M, p.Cout, p.bias, nullptr, y, p.relu, s);
+      return st;
+    }
     if (tail_tile == 0) return tsm::launch_conv(p, ks, s);
     int bm, bn;
     tsm::conv_tile_dims(main_tile, &bm, &bn);
@@ -371,15 +403,28 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     if (!tuning) {
       int code = tiles ? (*tiles)[idx] : 0;
       const char *force_code = getenv("TSM_CONV_CODE");  // tuning hook: force one tile code everywhere
-      if (force_code && tsm::conv_tile_valid(p, atoi(force_code) & 15)) code = atoi(force_code);
+      if (force_code && tsm::conv_tile_valid(p, atoi(force_code) & 15)) {
+        code = atoi(force_code);   // (launch_code ignores the split bit where it does not apply)
+      }
       TSM_LAUNCH_K(e, s, is3x3, launch_code(p, ks, code));
       return TSM_OK;
     }
     float best_ms = 0.f;
     int best = 0;
     std::vector<int> cands;
-    for (int t = 1; t < tsm::kNumTiles; ++t)
-      if (tsm::conv_tile_valid(p, t)) cands.push_back(t);
+    if (p.kseg_len > 0) {
+      // segmented layers: 64x64 / 32x32 tiles, whole-K or split-K (when the segment sums fit the scratch buffer and
+      // whole-K tiles alone would leave CUs idle or nearly so)
+      const size_t need = (size_t)tsm::conv_num_segments(p) * p.M * p.Cout;
+      const long tiles64 = (long)((p.M + 63) / 64) * (p.Cout / 64);
+      for (int t : {(int)tsm::kTile64x64, (int)tsm::kTile32x32}) {
+        cands.push_back(t);
+        if (need <= e->partial_elems && tiles64 < 4L * e->n_cu) cands.push_back(t | 0x100);
+      }
+    } else {
+      for (int t = 1; t < tsm::kNumTiles; ++t)
+        if (tsm::conv_tile_valid(p, t)) cands.push_back(t);
+    }
     // The coarse + tail code (64x64 rounds, 32x32 single-wave tiles for the leftover rows on stream2) is NOT
     // a candidate: measured slower than plain 64x64 on every layer at batch 32 (layer4 conv2 522 vs 489 us),
     // see DESIGN.md; TSM_CONV_CODE=67 still forces it for experiments.
@@ -451,7 +496,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     tsm::ConvParams p3 = make_params(c3, t2, fused ? nullptr : identity, out, n, ho, wo, true, 0, 1, prec);
     if (fused) {
       const ConvLayer &cd = e->convs[blk.down];
-      p3.w = blk.d_wf; p3.bias = blk.d_bf; p3.Kp = blk.kpf; p3.K1 = c3.kp;
+      p3.w = blk.d_wf; p3.bias = blk.d_bf; p3.Kp = blk.kpf; p3.K1 = c3.kp; p3.kseg_len = blk.ksegf;
       p3.x2 = cur; p3.C2 = cd.cp; p3.Hi2 = h; p3.Wi2 = w; p3.stride2 = blk.stride;
     }
     int rc3 = conv(blk.conv3, p3, 1, false);
@@ -630,6 +675,7 @@ int tsm_finalize(tsm_engine *e) {
     if (blk.down < 0 || !e->fuse_down) continue;
     const ConvLayer &c3 = e->convs[blk.conv3], &cd = e->convs[blk.down];
     blk.kpf = c3.kp + cd.kp;
+    blk.ksegf = segment_len(blk.kpf, e->prec);
     std::vector<float> wf((size_t)c3.cout * blk.kpf), bf(c3.cout);
     for (int o = 0; o < c3.cout; ++o) {
       std::memcpy(&wf[(size_t)o * blk.kpf], &host_wp[blk.conv3][(size_t)o * c3.kp], c3.kp * sizeof(float));
@@ -681,6 +727,11 @@ int tsm_finalize(tsm_engine *e) {
   if (rc) return rc;
   rc = dev_alloc(e, &e->d_logits, (size_t)cfg.max_clips * cfg.num_class);
   if (rc) return rc;
+  if (e->prec == tsm::kPrecF32) {  // split-K scratch: 64 MB covers the small-batch cases where split-K can win
+    e->partial_elems = (size_t)16 << 20;
+    rc = dev_alloc(e, &e->d_partial, e->partial_elems);
+    if (rc) return rc;
+  }
   e->tensors.clear();  // host copies are no longer needed
   e->finalized = true;
   return TSM_OK;

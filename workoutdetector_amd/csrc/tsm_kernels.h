@@ -33,6 +33,14 @@ struct ConvParams {
   // Row range of this launch, [m_begin, m_end) of the M output pixels (m_end <= 0: all of them).  Lets a
   // layer be covered by two launches with different tile shapes (coarse tiles + fine tiles for the tail).
   int m_begin, m_end;
+  // Segmented K accumulation (fp32, 64x64 / 32x32 tiles): kseg_len > 0 sums K in consecutive segments of kseg_len
+  // K-steps, each from a zero accumulator, and adds the segment sums in order:  out = ((0 + s0) + s1) + ...
+  // This fixes the summation order independently of how the work is launched, so the SAME layer can run as one
+  // workgroup per tile (ksplit = 0) or as one workgroup per (tile, segment) writing raw partial tiles to
+  // y = partial[segment][M][Cout] (ksplit = 1; splitk_reduce then applies bias / residual / ReLU) with
+  // bit-identical results: split-K for small batches without giving up batch invariance.
+  int kseg_len;
+  int ksplit;
 };
 
 enum ConvPrec { kPrecF32 = 0, kPrecBf16x3 = 1, kPrecBf16 = 2 };
@@ -48,10 +56,15 @@ bool conv_tile_valid(const ConvParams &p, int tile);
 
 // ks in {1, 3, 7}.  Returns hipSuccess or the launch error.
 hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s);
+// Number of K segments of a launch with kseg_len > 0 (1 otherwise).
+int conv_num_segments(const ConvParams &p);
+// y = act(((p[0] + p[1]) + ...) + bias (+ res)) over fp32 partial tiles [n_seg][M*Cout] written by a ksplit launch.
+hipError_t launch_splitk_reduce(const float *partial, int n_seg, int64_t m, int cout, const float *bias,
+                                const float *res, float *y, int relu, hipStream_t s);
 // Tile rows the heuristics would pick (exposed for tests / DESIGN notes).
 void conv_tile_shape(const ConvParams &p, int *bm, int *bn);
 
-// prec == kPrecF32: dst is NHWC4 fp32; kPrecBf16x3: NHWC8 split-bf16 (32 B/pixel); kPrecBf16: NHWC8 bf16 (16 B).
+// prec == kPrecF32: dst is NHWC4 fp32; bf16 formats: one 8-element group per pixel PAIR (rows of ceil(w/2) groups).
 hipError_t launch_pack_input(const float *src, float *dst, int64_t n_frames, int h, int w,
                              int nchw, int prec, hipStream_t s);
 // fp32 [n8 * 8 channels] <-> the storage format of `prec` (kPrecBf16x3 or kPrecBf16)

@@ -91,8 +91,11 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 //                32-byte group [hi x8 | lo x8] (same 4 bytes per element, same byte offsets as fp32, so the
 //                loader is shared).  a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32
 //                accumulation: relative error ~2^-17 per product, three MFMAs at 16x the fp32-MFMA rate.
-template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false, int RKT = 1>
+template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false, int RKT = 1,
+          bool SEG = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p) {
+  static_assert(!SEG || (PREC == kPrecF32 && !RES && WGM * WGN <= 4 && BM == BN && BM <= 64),
+                "segmented K accumulation: fp32, 64x64 / 32x32 tiles, no residual (ConvParams::kseg_len)");
   static_assert(WGM * WGN == 4 || WGM * WGN == 1 || WGM * WGN == 8,
                 "4 waves per workgroup, 1 (32x32 small-M tiles) or 8 (128x128 with 4 waves per SIMD at 2 workgroups/CU)");
   constexpr int NT = 64 * WGM * WGN;   // threads per workgroup
@@ -134,7 +137,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
   // contiguous run of tiles, n fastest, so co-resident blocks re-use the same A panel from L2.
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int seg = 0;  // SEG + ksplit: the grid holds ntm * ntn tiles per K segment, segment-major
+  if (SEG && p.ksplit) {
+    seg = tile / (p.ntm * p.ntn);
+    tile -= seg * (p.ntm * p.ntn);
+  }
   const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
   const int m0 = p.m_begin + tm * BM, n0 = tn * BN;   // m_begin: this launch covers rows [m_begin, m_end)
 
@@ -510,20 +518,52 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
   //                        the next tile's first fragments (read right after the barrier)
   // One barrier per step suffices: tile kt+1 is complete in LDS before it, and nobody overwrites
   // buf[kt&1] before the next barrier.  The body is straight-line.
-  const int nk = p.Kp / KC;
+  // This workgroup multiplies K-steps [kt0, nk): all of K, or one segment of it (SEG + ksplit).
+  int kt0 = 0, nk = p.Kp / KC;
+  if (SEG && p.ksplit) {
+    kt0 = seg * p.kseg_len;
+    nk = kt0 + p.kseg_len < nk ? kt0 + p.kseg_len : nk;
+  }
+  // SEG: `acc` holds the running segment, `tot` the sum of the finished ones (segment boundaries sit at
+  // multiples of kseg_len from K-step 0 in both launch forms; kt0 is such a multiple).
+  f32x16 tot[SEG ? TM : 1][SEG ? TN : 1];
+  if constexpr (SEG) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot[i][j][e] = 0.f;
+  }
+  auto seg_flush = [&]() {
+    if constexpr (SEG) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          tot[i][j] += acc[i][j];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        }
+    }
+  };
+  // SEG loops are nested: the inner loop runs the K-steps of one segment, the flush sits between segments (kept
+  // out of the inner loop on purpose: inside it the compiler if-converts the flush and drains the MFMA chain on
+  // every K-step).  Without SEG there is a single pass over [kt0, nk).
+  const int seg_len = (SEG && p.kseg_len > 0) ? p.kseg_len : 0x3fffffff;
   if constexpr (DMA) {
-    const KStep k0 = kstep(0, nk);
+    const KStep k0 = kstep(kt0, nk);
 #pragma unroll
-    for (int it = 0; it < NITEMS; ++it) dma_item(k0, 0, it);
+    for (int it = 0; it < NITEMS; ++it) dma_item(k0, kt0, it);
   } else {
-    const KStep k0 = kstep(0, nk);
+    const KStep k0 = kstep(kt0, nk);
 #pragma unroll
-    for (int it = 0; it < NITEMS; ++it) gload_item(k0, 0, it);
+    for (int it = 0; it < NITEMS; ++it) gload_item(k0, kt0, it);
 #pragma unroll
     for (int it = 0; it < NITEMS; ++it) lstore_item(0, it);
-    const KStep k1 = kstep(1, nk);
+    const KStep k1 = kstep(kt0 + 1, nk);
 #pragma unroll
-    for (int it = 0; it < NITEMS; ++it) gload_item(k1, 1, it);
+    for (int it = 0; it < NITEMS; ++it) gload_item(k1, kt0 + 1, it);
   }
   __syncthreads();  // (waits for outstanding LDS-DMA too: it is a pending LDS write on the VM counter)
   if constexpr (BF) {
@@ -531,8 +571,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
     // and the buffer loads of tile kt+2; groups 2-3 run after the barrier and cover the next fragments.
     frag_load_bf(0, 0);
     frag_load_bf(0, 1);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+      const int cur = (kt - kt0) & 1;
       const KStep k2 = kstep(kt + 2, nk);
       frag_load_bf(cur, 2);
       frag_load_bf(cur, 3);
@@ -555,7 +595,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
   } else if constexpr (DMA) {
     f32x4 ra_[4], rb_[4];  // all four k-groups of this wave's A / B fragments (TM = TN = 1)
     const int fsw = (l31 >> 1) & 7;  // f(row) of this lane's fragment row (tile offsets are multiples of 32)
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk;) {
+    const int kend = (SEG && kt + seg_len < nk) ? kt + seg_len : nk;
+    for (; kt < kend; ++kt) {
       const KStep k1 = kstep(kt + 1, nk);
       {
         const float *As = smem + (wm * WTM + l31) * LDR;
@@ -582,9 +624,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
         }
       __syncthreads();  // vmcnt(0) + barrier: tile kt+1 is complete in LDS
     }
+    seg_flush();
+    }
   } else if constexpr (RK) {
     f32x4 ra_[4], rb_[4];  // all four k-groups of this wave's A / B fragments (TM = TN = 1)
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk;) {
+    const int kend = (SEG && kt + seg_len < nk) ? kt + seg_len : nk;
+    for (; kt < kend; ++kt) {
       const KStep k2 = kstep(kt + 2, nk);
       {
         const float *As = smem + (wm * WTM + l31) * kLds + half * 4;
@@ -615,11 +661,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
         }
       __syncthreads();  // tile kt+1 is complete in LDS
     }
+    seg_flush();
+    }
   } else if constexpr (!X3) {
     frag_load(0, 0, 0);
     frag_load(0, 1, 1);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
+    for (int kt = kt0; kt < nk;) {
+    const int kend = (SEG && kt + seg_len < nk) ? kt + seg_len : nk;
+    for (; kt < kend; ++kt) {
+      const int cur = (kt - kt0) & 1;
       const KStep k2 = kstep(kt + 2, nk);
       mfma_plain(0);
       frag_load(cur, 2, 0);
@@ -634,14 +684,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
       frag_load(cur ^ 1, 1, 1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    seg_flush();
+    }
   } else {
     // split-bf16: a K-step is two k16-groups of 3*TM*TN MFMAs (32 cycles each).  Group 0 carries the
     // ds_writes of tile kt+1 and the buffer loads of tile kt+2; group 1 is issued after the barrier and
     // covers the LDS latency of the next tile's fragments.  Same buffer/barrier reasoning as above.
     frag_load_x3(0, 0, 0);
     frag_load_x3(0, 1, 1);
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+      const int cur = (kt - kt0) & 1;
       const KStep k2 = kstep(kt + 2, nk);
       mfma_x3(0, 2 * NITEMS, [&](int it) {
         if (it < NITEMS) lstore_item(cur ^ 1, it);
@@ -660,23 +712,25 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
   // ---- epilogue ---------------------------------------------------------------------------------
   // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Stage the BM x BN tile in
   // LDS (all operand reads finished at the barrier above), then stream it out row-major.
-  float *Cs = smem;
+  float *Cs = smem;  // (SEG: every segment, the last one included, was flushed into tot after its inner loop)
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e)
-        Cs[(wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * CLD + wn * WTN + j * 32 + l31] = acc[i][j][e];
+        Cs[(wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * CLD + wn * WTN + j * 32 + l31] =
+            SEG ? tot[SEG ? i : 0][SEG ? j : 0][e] : acc[i][j][e];
   __syncthreads();
 
   // Stores go through a descriptor that ends at row M: rows past the end are dropped by the range
   // check, which keeps the epilogue branch-free (no per-pass wait on earlier stores).
+  const bool partial = SEG && p.ksplit;  // raw segment sums to y = partial[seg][M][Cout]: no bias, no ReLU
   const size_t y_bytes = ((size_t)p.m_end - m0) * p.Cout * EB;
   const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<char *>(p.y) + (size_t)m0 * p.Cout * EB, 0,
+      reinterpret_cast<char *>(p.y) + ((size_t)(partial ? seg : 0) * p.M + m0) * p.Cout * EB, 0,
       (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
-  const float floor_ = p.relu ? 0.f : -INFINITY;  // ReLU as a branch-free clamp
+  const float floor_ = (p.relu && !partial) ? 0.f : -INFINITY;  // ReLU as a branch-free clamp
   if constexpr (BF) {
     const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
     const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol + 4);
@@ -697,7 +751,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
       __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (rr * p.Cout + n0 + ecol) * 2, 0, 0);
     }
   } else if constexpr (!X3) {
-    const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
+    f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
+    if (partial) bias = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < EPASS; ++k) {
       const int rr = erow + k * RPP;
@@ -741,8 +796,47 @@ __global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p)
   }
 }
 
+int conv_num_segments(const ConvParams &p) {
+  if (p.kseg_len <= 0) return 1;
+  const int nk = p.Kp / kBK;
+  return (nk + p.kseg_len - 1) / p.kseg_len;
+}
+
+// Segmented-K instantiations (fp32, 64x64 / 32x32 tiles, no residual): one workgroup per tile, or per
+// (tile, segment) when p.ksplit is set.
+template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT>
+static hipError_t launch_conv_seg(ConvParams p, hipStream_t s) {
+  if constexpr (!((BM == 64 && BN == 64) || (BM == 32 && BN == 32))) {
+    return hipErrorInvalidValue;
+  } else {
+    p.ntm = (p.m_end - p.m_begin + BM - 1) / BM;
+    p.ntn = p.Cout / BN;
+    const dim3 grid((unsigned)(p.ntm * p.ntn * (p.ksplit ? conv_num_segments(p) : 1)));
+    const dim3 block(64 * WGM * WGN);
+    const char *rk_env = getenv("TSM_CONV_RK");
+    const int rk = rk_env ? atoi(rk_env) : 1;
+    if constexpr (KS == 1 && !SHIFT) {
+      if (p.x2) {
+        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecF32, true, 1, true>), grid, block, 0, s, p);
+        return hipGetLastError();
+      }
+    }
+    if (rk == 0)
+      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, false, kPrecF32, false, 0, true>), grid, block, 0, s, p);
+    else if (rk == 2)
+      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, false, kPrecF32, false, 2, true>), grid, block, 0, s, p);
+    else
+      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, false, kPrecF32, false, 1, true>), grid, block, 0, s, p);
+    return hipGetLastError();
+  }
+}
+
 template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES>
 static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
+  if (p.kseg_len > 0) {
+    if constexpr (!RES && KS != 7) return launch_conv_seg<BM, BN, WGM, WGN, KS, SHIFT>(p, s);
+    else return hipErrorInvalidValue;
+  }
   p.ntm = (p.m_end - p.m_begin + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   const dim3 grid((unsigned)(p.ntm * p.ntn));
@@ -830,6 +924,11 @@ static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
     if (!conv_tile_valid(p, p.tile)) return hipErrorInvalidValue;
     conv_tile_dims(p.tile, &bm, &bn);
   }
+  if (p.kseg_len > 0 && !(bm == 32 && bn == 32)) {  // segmented accumulation exists on 64x64 / 32x32 tiles only
+    bm = 64;
+    bn = 64;
+    if (p.tile == kTile128x128w8) p.tile = kTile64x64;
+  }
   if (bm == 32 && bn == 32) {
     if (p.prec != kPrecF32) return hipErrorInvalidValue;
     return launch_conv_t<32, 32, 1, 1, KS, SHIFT, RES>(p, s);
@@ -855,6 +954,8 @@ hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
   if (p.x2 && (ks != 1 || p.T > 0 || p.res || p.K1 % kc != 0 || p.C2 % kc != 0 || p.K1 + p.C2 != p.Kp || p.K1 != p.C))
     return hipErrorInvalidValue;
   if (p.prec != kPrecF32 && p.prec != kPrecBf16x3 && p.prec != kPrecBf16) return hipErrorInvalidValue;
+  if (p.kseg_len < 0 || (p.kseg_len > 0 && (p.prec != kPrecF32 || p.res || ks == 7))) return hipErrorInvalidValue;
+  if (p.ksplit && (p.kseg_len <= 0 || p.m_begin != 0 || p.m_end != p.M)) return hipErrorInvalidValue;
   if (p.prec != kPrecF32 && p.T > 0 && p.fold % 8 != 0) return hipErrorInvalidValue;
   // stem: 4 channels per pixel (3 + a zero); the bf16 formats read pixel pairs, which needs stride 2 / pad 3
   if (ks == 7 && (p.C != 4 || (p.prec != kPrecF32 && (p.stride != 2 || p.pad != 3)))) return hipErrorInvalidValue;
@@ -870,6 +971,41 @@ hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
     case 7: return p.res ? hipErrorInvalidValue : launch_conv_ks<7, false, false>(p, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-K reduction (fp32): the segment sums of a ksplit launch are added in segment order -- the order the
+// unsplit kernel uses -- then bias, residual and ReLU exactly as in the conv epilogue.  4 channels per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float *__restrict__ partial, int n_seg, int64_t n4,
+                                                            int64_t seg_stride4, int cout4,
+                                                            const float *__restrict__ bias, const float *__restrict__ res,
+                                                            float *__restrict__ y, int relu) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float floor_ = relu ? 0.f : -INFINITY;
+  const f32x4 *p4 = reinterpret_cast<const f32x4 *>(partial);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 t = p4[i];
+    for (int sgm = 1; sgm < n_seg; ++sgm) t += p4[i + sgm * seg_stride4];
+    f32x4 v = t + reinterpret_cast<const f32x4 *>(bias)[i % cout4];
+    if (res) v += reinterpret_cast<const f32x4 *>(res)[i];
+    v[0] = fmaxf(v[0], floor_);
+    v[1] = fmaxf(v[1], floor_);
+    v[2] = fmaxf(v[2], floor_);
+    v[3] = fmaxf(v[3], floor_);
+    reinterpret_cast<f32x4 *>(y)[i] = v;
+  }
+}
+
+static unsigned grid_for(int64_t total, int cap);
+
+hipError_t launch_splitk_reduce(const float *partial, int n_seg, int64_t m, int cout, const float *bias,
+                                const float *res, float *y, int relu, hipStream_t s) {
+  if (!partial || !bias || !y || n_seg < 1 || m <= 0 || cout <= 0 || cout % 4 != 0) return hipErrorInvalidValue;
+  const int64_t n4 = m * cout / 4;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n4, 2048)), dim3(256), 0, s, partial, n_seg, n4, n4, cout / 4,
+                     bias, res, y, relu);
+  return hipGetLastError();
 }
 
 // =============================================================================================
@@ -1202,6 +1338,8 @@ __global__ void __launch_bounds__(256) head_pool_kernel(const float *__restrict_
   if (t >= cg) return;
   const float *src = feat + ((size_t)b * rows * cg + t) * GF;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // rows are added in order; unrolled by 7 (49 = 7 x 7 at 224^2) so that the loads of a group are in flight together
+#pragma unroll 7
   for (int r = 0; r < rows; ++r) {
     float v[8];
     load_group<FMT>(src + (size_t)r * cg * GF, v);
@@ -1226,6 +1364,7 @@ __global__ void __launch_bounds__(64) head_fc_kernel(const float *__restrict__ p
   float s = 0.f;
   for (int k = lane * 4; k < c; k += 256) {
     f32x4 f = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
     for (int t = 0; t < n_segment; ++t) f += *reinterpret_cast<const f32x4 *>(pv + (size_t)t * c + k);
     const f32x4 w = *reinterpret_cast<const f32x4 *>(wv + k);
     s += (f[0] * w[0] + f[1] * w[1]) + (f[2] * w[2] + f[3] * w[3]);
