@@ -261,6 +261,15 @@ def test_split_k_is_bitwise_identical_to_whole_k(hip_lib, sd0, monkeypatch):
         assert np.array_equal(ref, outs[name]), name
 
 
+def test_warmup_tunes_every_bucket(hip_lib, sd0):
+    from workoutdetector_amd.engine import TsmEngine
+    eng = TsmEngine(height=64, width=64, max_clips=5, state_dict=sd0).warmup()
+    for n in (1, 2, 4, 5):
+        tiles = eng.conv_tiles(n)
+        assert tiles and all(v != 'heuristic' for k, v in tiles.items() if 'downsample' not in k), (n, tiles)
+    eng.close()
+
+
 def test_cached_split_choice_is_rechecked_against_the_scratch_size(hip_lib, sd0):
     """Tile choices are cached per power-of-two bucket of the clip count: a split-K choice tuned on 5 clips is reused
     for 8, where the segment sums of some layer no longer fit the scratch buffer -> that launch must fall back to the

@@ -180,6 +180,24 @@ class TsmEngine:
                                              out[s:s + n].data_ptr(), stream), self._h)
         return out
 
+    def warmup(self, batch_sizes: Optional[Sequence[int]] = None) -> 'TsmEngine':
+        """Run one forward per power-of-two bucket of the clip count (default: 1, 2, 4, ... max_clips) so that the
+        per-bucket tile / split-K autotuning (a few hundred ms each) happens now and not on the first real request."""
+        import torch
+        self._need_finalized()
+        if batch_sizes is None:
+            batch_sizes, b = [], 1
+            while b < self.max_clips:
+                batch_sizes.append(b)
+                b *= 2
+            batch_sizes.append(self.max_clips)
+        dev = torch.device('cuda', self.device)
+        for b in batch_sizes:
+            b = max(1, min(int(b), self.max_clips))
+            self.forward_device(torch.zeros((b, self.num_segments, 3, self.height, self.width), device=dev))
+        torch.cuda.synchronize(dev)
+        return self
+
     def forward_tap(self, clips: np.ndarray, stage: str) -> np.ndarray:
         """Activation after ``stage`` as NHWC float32 ndarray (parity tests)."""
         self._need_finalized()
