@@ -93,7 +93,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 //                accumulation: relative error ~2^-17 per product, three MFMAs at 16x the fp32-MFMA rate.
 template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false, int RKT = 1,
           bool SEG = false>
-__global__ void __launch_bounds__(64 * WGM * WGN) conv_igemm(const ConvParams p) {
+__global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) ? 5 : 1) conv_igemm(const ConvParams p) {
   static_assert(!SEG || (PREC == kPrecF32 && !RES && WGM * WGN <= 4 && BM == BN && BM <= 64),
                 "segmented K accumulation: fp32, 64x64 / 32x32 tiles, no residual (ConvParams::kseg_len)");
   static_assert(WGM * WGN == 4 || WGM * WGN == 1 || WGM * WGN == 8,
