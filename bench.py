@@ -154,6 +154,7 @@ def main():
         eng = TsmEngine(num_class=12, num_segments=T, height=H, width=W, max_clips=B, device=local_rank,
                         state_dict=sd, dtype=dtype)
         logits = torch.empty(B, 12, device='cuda')
+        eng.warmup([B])      # one-time tile / split-K autotuning of this batch size: initialisation, never a timed step
 
         def step():
             eng.forward_device(clips, out=logits)

@@ -929,6 +929,13 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
   if (prec == tsm::kPrecBf16x3) to_split(&wp);
   if (prec == tsm::kPrecBf16) to_bf16(&wp);
   float *d_w = nullptr, *d_b = nullptr, *d_x4 = nullptr, *d_xs = nullptr, *d_rs = nullptr, *d_ys = nullptr;
+  struct Scratch {  // frees the temporaries on every exit path (errors included)
+    float **ptrs[6];
+    ~Scratch() {
+      for (float **q : ptrs)
+        if (*q) (void)hipFree(*q);
+    }
+  } scratch{{&d_w, &d_b, &d_x4, &d_xs, &d_rs, &d_ys}};
   TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_w), wp.size() * sizeof(float)));
   TSM_HIP0(hipMalloc(reinterpret_cast<void **>(&d_b), bias.size() * sizeof(float)));
   TSM_HIP0(hipMemcpy(d_w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -962,12 +969,6 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
   hipError_t st = tsm::launch_conv(p, k, s);
   if (st == hipSuccess && x3) st = tsm::launch_to_f32(d_ys, y, (int64_t)out_elems / 8, prec, s);
   hipError_t st2 = hipStreamSynchronize(s);
-  (void)hipFree(d_w);
-  (void)hipFree(d_b);
-  if (d_x4) (void)hipFree(d_x4);
-  if (d_xs) (void)hipFree(d_xs);
-  if (d_rs) (void)hipFree(d_rs);
-  if (d_ys) (void)hipFree(d_ys);
   if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,
                                     std::string("launch_conv: ") + hipGetErrorString(st));
   if (st2 != hipSuccess) return fail(nullptr, TSM_ERR_HIP, std::string("conv sync: ") + hipGetErrorString(st2));
