@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 GFLOP_PER_CLIP_T8_224 = 65.395          # 2 * (4.0871 GMAC/frame + 24576) * 8, SURVEY.md section 8(d)
 PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA", dense
+PEAK_HBM_GBS = 8000.0                   # MI355X_MICROARCH.md, HBM3E ~8 TB/s
 
 
 def flops_per_clip(t, h, w, num_class=12):
@@ -71,7 +72,7 @@ def measured_traffic(b, t, h, w, kernel):
         c = e.get('config', {})
         if ((c.get('clips_per_gpu'), c.get('num_segments'), c.get('height'), c.get('width')) == (b, t, h, w)
                 and e.get('kernel') == kernel):
-            return e.get('hbm_bytes_per_launch')
+            return e
     return None
 
 
@@ -109,7 +110,13 @@ def main():
     ap.add_argument('--no-alt', action='store_true', help='skip the second run in the other precision mode')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16x3', 'bf16'],
                     help='f32: exact-fp32 MFMA; bf16x3: split-bf16 storage, 3 bf16 MFMAs per product')
+    ap.add_argument('--config', type=int, default=2, choices=[2, 5],
+                    help='BASELINE.json configuration: 2 = the headline defaults; 5 = T=16, 256x256, 64 clips per GPU, '
+                         'TSM_DTYPE_BF16 (sets --dtype/--batch/--segments/--size, skips the alt run and the CPU baseline)')
     args = ap.parse_args()
+    if args.config == 5:
+        args.dtype, args.batch, args.segments, args.size = 'bf16', 64, 16, 256
+        args.no_alt = args.no_cpu_baseline = True
 
     import torch
     import torch.distributed as dist
@@ -241,19 +248,20 @@ def main():
                      else 'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), dense')
         dom_avg_ms = sum(dom_ms) / len(dom_ms)
         achieved = dom_gflop / dom_avg_ms
+        traffic_entry = measured_traffic(B, T, H, W, dom_kernel)
         line = {
             'metric': f'clips/sec ({T}x3x{H}x{W} TSM-R50)', 'value': round(value, 2), 'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'TSM-R50 {T}-seg {H}x{W} 12-class inference, batch {B} clips per GPU, ' +
-                                   '%s NHWC, device-resident input (BASELINE.json configs[1])' % args.dtype,
+                                   '%s NHWC, device-resident input (BASELINE.json configs[%d])' % (args.dtype, 4 if args.config == 5 else 1),
                        'clips_per_gpu': B, 'num_segments': T, 'height': H, 'width': W, 'num_class': 12,
                        'weights': 'seeded random init (no trained weights offline)',
                        'parallelism': f'clip-sharded x{world}, RCCL all-gather of logits' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                         'traffic': measured_traffic(B, T, H, W, dom_kernel),
+                         'traffic': (traffic_entry or {}).get('hbm_bytes_per_launch'),
                          'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/traffic.json)',
                          'kernel': dom_kernel + ' (3x3 convs of layer2-4, %d of 13 launches per forward%s)'
                                    % (len(dom_ms) // len(per_launch),
@@ -266,6 +274,12 @@ def main():
                          'forward_frac': round(fwd_achieved / peak, 4),
                          'forward_gflop': round(gflop * B, 3), 'forward_kernel_ms': round(fwd_ms, 4)},
         }
+        if traffic_entry and traffic_entry.get('forward_hbm_bytes'):
+            # whole-forward HBM rate from the committed PMC passes (bytes) over the live forward time: the second
+            # roofline SURVEY 8d asks for beside the MFMA one (matters for the bf16 formats)
+            gbs = traffic_entry['forward_hbm_bytes'] / 1e9 / (fwd_ms / 1e3)
+            line['roofline'].update({'forward_hbm_gbs': round(gbs, 1), 'forward_hbm_frac': round(gbs / PEAK_HBM_GBS, 4),
+                                     'hbm_peak_gbs': PEAK_HBM_GBS})
         if world > 1:
             line['exchange'] = {'collective': 'all_gather_into_tensor of f32[%d, 12] per rank (RCCL)' % B,
                                 'avg_us': round(exchange_us[args.dtype], 1),
