@@ -142,3 +142,51 @@ def test_stream_batcher_on_gpu_engine(probe_engine):
         assert len(states) == len(v) // 8
         assert res32[k] == pred_to_count(states, 8) == counting_oracle.pred_to_count(states, 8)
     assert res32['a'][0] >= 5 and res32['b'][0] >= 3
+
+
+def _gpu_dataset_worker(rank, world, port, root, out_dir, shard):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)       # one GPU on the test box: gloo, both ranks on cuda:0
+    try:
+        from workoutdetector_amd import inference_count as ic
+        from workoutdetector_amd.engine import TsmEngine
+        from workoutdetector_amd.weights import make_state_dict
+        eng = TsmEngine(num_class=12, max_clips=8, state_dict=make_state_dict(0, 12))
+        ic.inference_dataset(eng, ['test'], out_dir, checkpoint='seed0', data_root=root, batch_clips=8, shard=shard)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('shard', ['clips', 'videos'])
+def test_two_rank_dataset_inference_with_real_engines(hip_lib, tmp_path, golden_dir, shard):
+    """The N > 1 dataset path with REAL engines: two processes (gloo; both on the box's single GPU), clips or whole
+    videos sharded, logits all-gathered, rank 0 writes -- JSON identical to the single-process run, bit for bit
+    (batch invariance makes the per-rank batch shapes irrelevant)."""
+    import socket
+
+    import pandas as pd
+    import torch.multiprocessing as mp
+    from workoutdetector_amd import inference_count as ic
+    from workoutdetector_amd.engine import TsmEngine
+    from workoutdetector_amd.weights import make_state_dict
+    anno = pd.read_csv(f'{golden_dir}/repcount_annotation.csv', index_col=0)
+    rows = anno[anno['name'].isin(['stu1_40.mp4', 'stu5_32.mp4', 'stu3_53.mp4'])].copy()
+    rows['name'] = [n.replace('.mp4', '.npy') for n in rows['name']]
+    root = tmp_path / 'RepCount'
+    (root / 'videos' / 'test').mkdir(parents=True)
+    rows.to_csv(root / 'annotation.csv')
+    for i, name in enumerate(rows['name']):
+        np.save(root / 'videos' / 'test' / name, synthetic_video(60 + i, (90, 17, 41)[i], 96, 64, period=20))
+    single, sharded = str(tmp_path / 'single'), str(tmp_path / 'sharded')
+    eng = TsmEngine(num_class=12, max_clips=8, state_dict=make_state_dict(0, 12))
+    ic.inference_dataset(eng, ['test'], single, checkpoint='seed0', data_root=str(root), batch_clips=8)
+    eng.close()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gpu_dataset_worker, args=(2, port, str(root), sharded, shard), nprocs=2, join=True)
+    assert sorted(os.listdir(single)) == sorted(os.listdir(sharded)) and len(os.listdir(single)) == 3
+    for f in os.listdir(single):
+        assert json.load(open(os.path.join(single, f))) == json.load(open(os.path.join(sharded, f))), f
