@@ -6,10 +6,13 @@
 //                    layout (128x128 on 4 or 8 waves, 128x64, 64x64, 32x32 on one wave), KS, SHIFT (fused
 //                    temporal shift), RES (residual prefetched under the K loop), PREC (exact-fp32 MFMA /
 //                    split-bf16 x3 / bf16), DUAL (second A source concatenated along K = conv3 + downsample in
-//                    one GEMM), RKT (fp32 64x64 pipeline: 2 LDS buffers / register-resident K-step / LDS-DMA).
+//                    one GEMM), RKT (fp32 64x64 pipeline: 2 LDS buffers / register-resident K-step / LDS-DMA),
+//                    SEG (fp32 long-K layers: K summed in fixed segments, which makes whole-K and split-K
+//                    launches of a layer bit-identical; splitk_reduce adds the segment sums in order).
 //                    Every variant accumulates each output in the same k order: results are bit-identical
-//                    across tile shapes and pipelines of one precision.
-//   pack_input       [N,3,H,W] or [N,H,W,3] fp32 -> one channel group per pixel in the engine's storage format
+//                    across tile shapes, pipelines and launch forms of one precision.
+//   pack_input       [N,3,H,W] or [N,H,W,3] fp32 -> the stem's input format (fp32: one 4-channel group per pixel;
+//                    bf16 formats: one 8-element group per pixel pair)
 //   preprocess       fused test transform: uint8/fp32 frames -> resize 256 / crop 224 / normalise -> packed input
 //   maxpool3x3s2     NHWC, any storage format
 //   temporal_shift   stand-alone NHWC fp32 shift (tests; the forward uses the fused loader)
@@ -93,6 +96,8 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 //                accumulation: relative error ~2^-17 per product, three MFMAs at 16x the fp32-MFMA rate.
 template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false, int RKT = 1,
           bool SEG = false>
+// (second launch-bounds argument = minimum waves per SIMD: the SEG 64x64 kernel needs 16 registers more than the
+// plain one and would drop from 5 to 4 workgroups per CU; asking for 5 costs 1-2 spills outside the K loop)
 __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) ? 5 : 1) conv_igemm(const ConvParams p) {
   static_assert(!SEG || (PREC == kPrecF32 && !RES && WGM * WGN <= 4 && BM == BN && BM <= 64),
                 "segmented K accumulation: fp32, 64x64 / 32x32 tiles, no residual (ConvParams::kseg_len)");
