@@ -41,8 +41,8 @@ PEAK_HBM_GBS = 8000.0                   # MI355X_MICROARCH.md, HBM3E ~8 TB/s
 
 
 def flops_per_clip(t, h, w, num_class=12):
-    from oracle.tsm_oracle import macs_per_frame
-    return 2.0 * macs_per_frame(h, w, num_class) * t
+    from workoutdetector_amd.flops import flops_per_clip as f   # algorithmic work, SURVEY section 8d
+    return f(t, h, w, num_class)
 
 
 def host_cores():
@@ -236,7 +236,7 @@ def main():
         value = clips_total / elapsed
         gflop = flops_per_clip(T, H, W) / 1e9
         fwd_achieved = gflop * B / fwd_ms  # GFLOP / ms == TFLOP/s
-        from oracle.tsm_oracle import layer_table
+        from workoutdetector_amd.flops import layer_table
         frames = B * T
         dom = [r for r in layer_table(H, W) if r['k'] == 3 and r['s'] >= 1 and not r['name'].startswith('layer1.')]
         dom_gflop = {2.0 * r['macs'] * frames / 1e9 for r in dom}

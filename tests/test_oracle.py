@@ -80,3 +80,15 @@ def test_transform_oracle_shapes_and_quirk():
     v = transform_oracle.clip_to_input(grey)[0, 0, :, 100, 100]
     np.testing.assert_allclose(v.numpy(), [(128 - m) / s for m, s in zip(transform_oracle.MEAN, transform_oracle.STD)],
                                rtol=1e-6)
+
+
+def test_product_flop_accounting_equals_the_oracle_table():
+    """bench.py prices its roofline with workoutdetector_amd.flops (the oracle is only its cpu_baseline leg): that
+    table, derived from weights.conv_specs(), must equal the oracle's independently written one on every shape."""
+    from workoutdetector_amd import flops
+    for hw in [(224, 224), (256, 256), (96, 128), (225, 640), (64, 64)]:
+        a = {r['name']: r for r in flops.layer_table(*hw)}
+        b = {r['name']: r for r in tsm_oracle.layer_table(*hw)}
+        assert a == b, hw
+        assert flops.macs_per_frame(*hw, num_class=7) == tsm_oracle.macs_per_frame(*hw, num_class=7)
+    assert flops.flops_per_clip(8, 224, 224, 12) / 1e9 == 65.394573312

@@ -7,7 +7,7 @@ import sys
 import os
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.tsm_oracle import layer_table  # noqa: E402
+from workoutdetector_amd.flops import layer_table  # noqa: E402
 
 
 def read_rows(path):
