@@ -283,3 +283,29 @@ def test_cached_split_choice_is_rechecked_against_the_scratch_size(hip_lib, sd0)
     one = eng.run(None, {'input': x[7:8]})[0]
     assert np.array_equal(one[0], eight[7])
     eng.close()
+
+
+def test_tune_cache_file_round_trip(hip_lib, sd0, tmp_path, monkeypatch):
+    """TSM_TUNE_CACHE: the first engine tunes and appends one line per bucket; a second engine (a later process in
+    practice) reads the codes instead of timing again; a corrupt file is ignored; results are identical either way."""
+    from workoutdetector_amd.engine import TsmEngine
+    path = tmp_path / 'tiles.txt'
+    monkeypatch.setenv('TSM_TUNE_CACHE', str(path))
+    x = make_input(51, 3, 8, 96, 96)
+    a = TsmEngine(height=96, width=96, max_clips=4, state_dict=sd0)
+    ya = a.run(None, {'input': x})[0]
+    tiles_a = a.conv_tiles(3)
+    a.close()
+    lines = path.read_text().splitlines()
+    assert len(lines) == 1 and ' 96x96 ' in lines[0] and lines[0].count('|') == 2
+    b = TsmEngine(height=96, width=96, max_clips=4, state_dict=sd0)
+    yb = b.run(None, {'input': x})[0]
+    assert b.conv_tiles(3) == tiles_a and np.array_equal(ya, yb)
+    b.run(None, {'input': x[:1]})                              # another bucket: tuned and appended
+    b.close()
+    assert len(path.read_text().splitlines()) == 2
+    path.write_text(lines[0].rsplit('|', 1)[0] + '|9999,abc\n')     # same key, malformed codes
+    c = TsmEngine(height=96, width=96, max_clips=4, state_dict=sd0)
+    assert np.array_equal(c.run(None, {'input': x})[0], ya)          # ignored -> tuned again -> appended
+    c.close()
+    assert len(path.read_text().splitlines()) == 2

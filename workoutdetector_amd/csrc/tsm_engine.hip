@@ -169,6 +169,10 @@ struct tsm_engine {
   std::map<int, std::vector<int>> tile_cache;
   bool autotune = true;
   bool fuse_down = true;  // TSM_FUSE_DOWNSAMPLE=0 runs the downsample branch as its own launch
+  // TSM_TUNE_CACHE=<file>: tuned tile codes are appended to / read from this file, one line per bucket, keyed by
+  // `tune_sig` (ABI, device name, geometry, dtype): a later process skips the timing pass.  Codes never change
+  // results, so a stale or foreign line can only cost speed; malformed lines are ignored.
+  std::string tune_path, tune_sig;
   // tail launches: fine (32x32, one wave) tiles for the rows the coarse tiles cannot spread evenly over the
   // CUs, issued on a second stream so that they overlap the coarse launch
   hipStream_t stream2 = nullptr;
@@ -294,6 +298,47 @@ int tile_bucket(int n_clips) {
   int b = 1;
   while (b < n_clips) b <<= 1;
   return b;
+}
+
+bool tune_cache_load(tsm_engine *e, int key, std::vector<int> *codes) {
+  if (e->tune_path.empty()) return false;
+  FILE *f = fopen(e->tune_path.c_str(), "r");
+  if (!f) return false;
+  const std::string want = e->tune_sig + "|" + std::to_string(key) + "|";
+  char line[4096];
+  bool ok = false;
+  while (!ok && fgets(line, sizeof line, f)) {
+    if (strncmp(line, want.c_str(), want.size()) != 0) continue;
+    std::vector<int> got;
+    const char *q = line + want.size();
+    while (*q && *q != '\n') {
+      char *end = nullptr;
+      const long v = strtol(q, &end, 10);
+      if (end == q) break;
+      const int main_tile = (int)(v & 15), tail = (int)((v >> 4) & 15);
+      if (v < 0 || v >= 0x200 || main_tile >= tsm::kNumTiles || tail >= tsm::kNumTiles) { got.clear(); break; }
+      got.push_back((int)v);
+      q = (*end == ',') ? end + 1 : end;
+    }
+    if (got.size() == codes->size()) {
+      *codes = got;
+      ok = true;
+    }
+  }
+  fclose(f);
+  return ok;
+}
+
+void tune_cache_store(tsm_engine *e, int key, const std::vector<int> &codes) {
+  if (e->tune_path.empty()) return;
+  std::string line = e->tune_sig + "|" + std::to_string(key) + "|";
+  for (size_t i = 0; i < codes.size(); ++i) line += (i ? "," : "") + std::to_string(codes[i]);
+  line += "\n";
+  if (line.size() >= 4096) return;
+  FILE *f = fopen(e->tune_path.c_str(), "a");   // one short write per line: appends from several ranks do not interleave
+  if (!f) return;
+  fwrite(line.data(), 1, line.size(), f);
+  fclose(f);
 }
 
 struct Tap {
@@ -578,6 +623,15 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
             : cfg->dtype == TSM_DTYPE_BF16 ? tsm::kPrecBf16 : tsm::kPrecF32;
   if (const char *at = getenv("TSM_AUTOTUNE")) e->autotune = atoi(at) != 0;
   if (const char *fd = getenv("TSM_FUSE_DOWNSAMPLE")) e->fuse_down = atoi(fd) != 0;
+  if (const char *tc = getenv("TSM_TUNE_CACHE")) {
+    hipDeviceProp_t prop;
+    e->tune_path = tc;
+    e->tune_sig = "abi" + std::to_string(TSM_ABI_VERSION) + " " +
+                  (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess ? std::string(prop.gcnArchName) : "?") +
+                  " T" + std::to_string(cfg->num_segments) + " " + std::to_string(cfg->height) + "x" +
+                  std::to_string(cfg->width) + " dtype" + std::to_string(cfg->dtype) + " shift" +
+                  std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0);
+  }
   build_topology(e);
   st = hipSetDevice(cfg->device_id);
   if (st == hipSuccess) st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -760,12 +814,19 @@ int tsm_forward(tsm_engine *e, const void *clips, int32_t memkind, int32_t layou
   }
   // A forward that still has to tune its tile shapes does so in a throw-away pass first (it uses the
   // timing events and synchronises); the real pass below then runs from the cache.
-  if (e->autotune && e->tile_cache.find(tile_bucket(n_clips) * e->cfg.num_segments) == e->tile_cache.end()) {
-    std::vector<hipEvent_t> *saved = e->cur_timing;
-    e->cur_timing = nullptr;
-    rc = run_forward(e, d_clips, layout, n_clips, d_out, s, nullptr, nullptr);
-    e->cur_timing = saved;
-    if (rc) return rc;
+  const int tune_key = tile_bucket(n_clips) * e->cfg.num_segments;
+  if (e->autotune && e->tile_cache.find(tune_key) == e->tile_cache.end()) {
+    std::vector<int> cached(e->convs.size(), 0);
+    if (tune_cache_load(e, tune_key, &cached)) {
+      e->tile_cache.emplace(tune_key, cached);          // tuned by an earlier process (TSM_TUNE_CACHE)
+    } else {
+      std::vector<hipEvent_t> *saved = e->cur_timing;
+      e->cur_timing = nullptr;
+      rc = run_forward(e, d_clips, layout, n_clips, d_out, s, nullptr, nullptr);
+      e->cur_timing = saved;
+      if (rc) return rc;
+      tune_cache_store(e, tune_key, e->tile_cache[tune_key]);
+    }
   }
   TSM_HIP(e, hipEventRecord(e->ev0, s));
   rc = run_forward(e, d_clips, layout, n_clips, d_out, s, nullptr, nullptr);
