@@ -633,8 +633,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
     }
   } else if constexpr (RK) {
     f32x4 ra_[4], rb_[4];  // all four k-groups of this wave's A / B fragments (TM = TN = 1)
-    for (int kt = kt0; kt < nk;) {
-    const int kend = (SEG && kt + seg_len < nk) ? kt + seg_len : nk;
+    // fp32 stem: K = 49 taps x 4 channels = 196 of the 224 padded, so the last K-step holds real data in its first
+    // 4 k only: it runs as a 4-MFMA tail instead of 16 (the 12 skipped MFMAs multiply zeros; same bits).
+    const bool trim = KS == 7 && p.Kp == 224 && nk == 7;
+    const int nk_full = trim ? nk - 1 : nk;
+    for (int kt = kt0; kt < nk_full;) {
+    const int kend = (SEG && kt + seg_len < nk_full) ? kt + seg_len : nk_full;
     for (; kt < kend; ++kt) {
       const KStep k2 = kstep(kt + 2, nk);
       {
@@ -667,6 +671,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
       __syncthreads();  // tile kt+1 is complete in LDS
     }
     seg_flush();
+    }
+    if (KS == 7 && trim) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(smem + (wm * WTM + l31) * kLds + half * 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(smem + BM * kLds + (wn * WTN + l31) * kLds + half * 4);
+      __syncthreads();  // fragments are in registers: the epilogue may reuse the buffer
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s4], b0[s4], acc[0][0], 0, 0, 0);
     }
   } else if constexpr (!X3) {
     frag_load(0, 0, 0);
