@@ -100,3 +100,23 @@ def test_tile_choice_is_bitwise_neutral_in_bf16_modes(hip_lib, sd0, monkeypatch,
         eng.close()
     for name in outs:
         assert np.array_equal(outs['tuned'], outs[name]), name
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('n,hi,wi', [(2, 32, 32), (3, 45, 37), (4, 96, 96), (2, 224, 224), (1, 70, 250), (17, 40, 34)])
+def test_direct_stem_equals_the_generic_kernel_bitwise(hip_lib, monkeypatch, dtype, n, hi, wi):
+    """The dedicated stem of the bf16 formats (direct conv from an LDS-resident pixel-pair patch, persistent workgroups)
+    against the generic implicit-GEMM kernel on the same packed weights: same K order per output -> same bits,
+    including ragged tiles (sizes that are not multiples of the 8x16 tile), odd widths and more tiles than workgroups."""
+    from workoutdetector_amd.engine import conv_bn_act_nhwc
+    g = torch.Generator().manual_seed(500 + hi + wi)
+    x = _nhwc(torch.randn(n, 3, hi, wi, generator=g)).cuda()
+    w = (torch.randn(64, 3, 7, 7, generator=g) * (2.0 / 147) ** 0.5).cuda()
+    bn = [b.cuda() for b in _bn(64, g)]
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('TSM_STEM_DIRECT', flag)
+        for relu in (True, False):
+            outs[flag, relu] = conv_bn_act_nhwc(x, w, *bn, stride=2, relu=relu, dtype=dtype).cpu()
+    for relu in (True, False):
+        assert torch.equal(outs['1', relu], outs['0', relu]), relu

@@ -169,6 +169,7 @@ struct tsm_engine {
   std::map<int, std::vector<int>> tile_cache;
   bool autotune = true;
   bool fuse_down = true;  // TSM_FUSE_DOWNSAMPLE=0 runs the downsample branch as its own launch
+  bool stem_direct = true;  // TSM_STEM_DIRECT=0: bf16-format stems on the generic implicit-GEMM kernel (bit-identical, slower)
   // TSM_TUNE_CACHE=<file>: tuned tile codes are appended to / read from this file, one line per bucket, keyed by
   // `tune_sig` (ABI, device name, geometry, dtype): a later process skips the timing pass.  Codes never change
   // results, so a stale or foreign line can only cost speed; malformed lines are ignored.
@@ -506,8 +507,14 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   float *cur = e->buf[0], *out = e->buf[1], *t1 = e->buf[2], *t2 = e->buf[3], *idb = e->buf[4];
   {
     tsm::ConvParams p = make_params(e->convs[0], in4, nullptr, t1, n, cfg.height, cfg.width, true, 0, 1, prec);
-    int rc0 = conv(0, p, 7, false);
-    if (rc0) return rc0;
+    // bf16 formats: dedicated direct-conv stem (LDS-resident input patch); TSM_STEM_DIRECT=0 keeps the generic kernel
+    if (prec != tsm::kPrecF32 && e->stem_direct) {
+      TSM_LAUNCH(e, s, tsm::launch_stem_direct(in4, e->convs[0].d_w, e->convs[0].d_b, t1, n, cfg.height, cfg.width,
+                                                e->convs[0].kp, 1, prec, s));
+    } else {
+      int rc0 = conv(0, p, 7, false);
+      if (rc0) return rc0;
+    }
     if (want("conv1")) return hit(t1, n, e->h1, e->w1, 64);
     TSM_LAUNCH(e, s, tsm::launch_maxpool3x3s2(t1, cur, n, e->h1, e->w1, 64, prec, s));
     if (want("stem")) return hit(cur, n, e->hp, e->wp, 64);
@@ -623,6 +630,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
             : cfg->dtype == TSM_DTYPE_BF16 ? tsm::kPrecBf16 : tsm::kPrecF32;
   if (const char *at = getenv("TSM_AUTOTUNE")) e->autotune = atoi(at) != 0;
   if (const char *fd = getenv("TSM_FUSE_DOWNSAMPLE")) e->fuse_down = atoi(fd) != 0;
+  if (const char *sd = getenv("TSM_STEM_DIRECT")) e->stem_direct = atoi(sd) != 0;
   if (const char *tc = getenv("TSM_TUNE_CACHE")) {
     hipDeviceProp_t prop;
     e->tune_path = tc;
@@ -1027,7 +1035,12 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
   }
   tsm::ConvParams p = make_params(c, xin, rin, yout, n, hi, wi, relu != 0, shift_segments,
                                   fold_div > 0 ? fold_div : 1, prec);
-  hipError_t st = tsm::launch_conv(p, k, s);
+  const char *sd_env = getenv("TSM_STEM_DIRECT");
+  hipError_t st;
+  if (stem && x3 && cout == 64 && !(sd_env && atoi(sd_env) == 0))
+    st = tsm::launch_stem_direct(xin, c.d_w, c.d_b, yout, n, hi, wi, c.kp, relu != 0, prec, s);
+  else
+    st = tsm::launch_conv(p, k, s);
   if (st == hipSuccess && x3) st = tsm::launch_to_f32(d_ys, y, (int64_t)out_elems / 8, prec, s);
   hipError_t st2 = hipStreamSynchronize(s);
   if (st != hipSuccess) return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,

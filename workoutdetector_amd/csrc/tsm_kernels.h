@@ -56,6 +56,11 @@ bool conv_tile_valid(const ConvParams &p, int tile);
 
 // ks in {1, 3, 7}.  Returns hipSuccess or the launch error.
 hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s);
+// Stem (7x7 s2 p3, 3 -> 64) of the bf16 formats as a direct convolution from an LDS-resident pixel-pair patch; x is the
+// packed-pair input [n][hi][ceil(wi/2)][8], w the engine's packed stem weights [64][kp], y NHWC, all in `prec`'s format
+// (kPrecBf16 or kPrecBf16x3).  Bit-identical to launch_conv(ks = 7) on the same operands.
+hipError_t launch_stem_direct(const float *x, const float *w, const float *bias, float *y, int n, int hi, int wi, int kp,
+                              int relu, int prec, hipStream_t s);
 // Number of K segments of a launch with kseg_len > 0 (1 otherwise).
 int conv_num_segments(const ConvParams &p);
 // y = act(((p[0] + p[1]) + ...) + bias (+ res)) over fp32 partial tiles [n_seg][M*Cout] written by a ksplit launch.

@@ -991,6 +991,182 @@ hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// stem_direct: the 7x7 stride-2 stem of the bf16 formats as a direct convolution from an LDS-resident input patch.
+// The generic implicit-GEMM loader gathers 28 groups of 8 elements per output pixel from L2 (each input pixel pair
+// is fetched ~12 times): with 3 input channels that gather, not the MFMA or HBM, bounds the stem in these formats.
+// Here a persistent workgroup keeps the packed weights [64][224] in LDS and, per (2 * WAVES) x 16 tile of output
+// pixels, loads the (4 * WAVES + 5) x 19 pixel-pair patch it needs ONCE (prefetched into registers under the previous
+// tile), then builds every MFMA A fragment straight from that patch: with K ordered (ky, pair j, pixel-in-pair, c4) a
+// fragment (8 consecutive k) is exactly one group of the patch at row 2*oy + ky, pair ox + j.  14 k16-steps x 2
+// N-tiles per wave and tile, no barrier inside.  Same products in the same order per accumulator as conv_igemm's
+// stem (whose trailing all-zero K padding is skipped), so results are bit-identical to it.
+// ---------------------------------------------------------------------------------------------
+constexpr int kStemTW = 16, kStemPC = kStemTW + 3;  // output tile width; input patch width in pixel pairs (19)
+
+// X3 = false: TSM_DTYPE_BF16 (16-byte groups of 8 bf16);  true: split-bf16 (32-byte groups [hi x8 | lo x8], three
+// MFMAs per product in conv_igemm's order ah*bh, ah*bl, al*bh).
+// WAVES waves per workgroup, each owning 2 rows x 16 columns of the (2 * WAVES) x 16 output tile: 4 for bf16 (75 KB of
+// LDS, two workgroups per CU), 8 for split-bf16 (one 159-KB workgroup per CU, two waves per SIMD).
+template <bool X3, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) stem_direct_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, float *__restrict__ y, int n,
+                                                          int hi, int wi, int ho, int wo, int kp, int relu) {
+  constexpr int NT = 64 * WAVES, kStemTH = 2 * WAVES, kStemPR = 2 * kStemTH + 5;  // threads; tile rows; patch rows
+  constexpr int GB = X3 ? 32 : 16;                    // bytes per 8-element group
+  // weight row stride in LDS: 28 groups + padding so that the rows of a 16-lane ds_read_b128 group fall on
+  // distinct 4-bank slots (stride in dwords = 4 mod 64)
+  constexpr int WROW = X3 ? 1040 : 528;
+  constexpr int OPX = X3 ? 256 : 128;                 // output bytes per pixel (64 channels)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * WROW + kStemPR * kStemPC * GB + 32 * WAVES * 68 * 4];
+  unsigned char *Ws = smem;
+  unsigned char *Ps = smem + 64 * WROW;
+  float *Cs = reinterpret_cast<float *>(smem + 64 * WROW + kStemPR * kStemPC * GB);  // [32 * WAVES][68] fp32 staging
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wpairs = (wi + 1) >> 1;
+
+  // weights -> LDS once per workgroup (64 rows x 28 groups)
+  constexpr int WCH = 28 * GB / 16;  // 16-byte chunks per row
+  for (int c = tid; c < 64 * WCH; c += NT) {
+    const int row = c / WCH, ch = c - row * WCH;
+    *reinterpret_cast<u32x4 *>(Ws + row * WROW + ch * 16) = *reinterpret_cast<const u32x4 *>(
+        reinterpret_cast<const unsigned char *>(w) + (size_t)row * kp * (GB / 8) + ch * 16);
+  }
+  const unsigned x_frame = (unsigned)hi * wpairs * GB, y_frame = (unsigned)ho * wo * OPX;  // bytes per frame
+  const float floor_ = relu ? 0.f : -INFINITY;
+
+  const int tiles_x = (wo + kStemTW - 1) / kStemTW, tiles_y = (ho + kStemTH - 1) / kStemTH;
+  const long n_tiles = (long)n * tiles_y * tiles_x;
+  // this lane's pixel inside the wave's 2 x 16 slice of the tile, and its A-fragment base inside the patch
+  const int pr = 2 * wave + (l31 >> 4), pc = l31 & 15;
+  const unsigned char *a_base = Ps + ((2 * pr) * kStemPC + pc) * GB;
+  const unsigned char *b_base = Ws + l31 * WROW;
+
+  // The patch of tile t+1 is fetched into registers while tile t is multiplied and stored (its global-load
+  // latency would otherwise be exposed once per tile: there is no K loop to hide it under).
+  constexpr int PCH = kStemPR * kStemPC * GB / 16;   // 16-byte chunks of a patch
+  constexpr int PPASS = (PCH + NT - 1) / NT;
+  u32x4 pre[PPASS];
+  auto fetch_patch = [&](long t) {
+    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+    const int iy0 = 2 * ty * kStemTH - 3, pc0 = tx * kStemTW - 2;
+    // descriptor rebased to the tile's frame: 32-bit offsets suffice whatever the batch
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(x) + (size_t)f * x_frame), 0, (int)x_frame, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q) {
+      const int ci = tid + q * NT;               // chunk index inside the patch
+      const int g = X3 ? ci >> 1 : ci;           // group index
+      const int r = g / kStemPC, c = g - r * kStemPC;
+      const int iy = iy0 + r, pcx = pc0 + c;
+      const bool ok = ci < PCH && (unsigned)iy < (unsigned)hi && (unsigned)pcx < (unsigned)wpairs;
+      const unsigned off = (unsigned)((iy * wpairs + pcx) * GB + (X3 ? (ci & 1) * 16 : 0));
+      pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)(ok ? off : kInvalid), 0, 0);
+    }
+  };
+  if ((long)blockIdx.x < n_tiles) fetch_patch(blockIdx.x);
+  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+    const int oy0 = ty * kStemTH, ox0 = tx * kStemTW;
+    const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(y) + (size_t)f * y_frame, 0, (int)y_frame, 0x00020000);
+    __syncthreads();  // previous tile's patch and staging are free (and the weights are in place)
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q)
+      if (tid + q * NT < PCH) *reinterpret_cast<u32x4 *>(Ps + (tid + q * NT) * 16) = pre[q];
+    if (t + gridDim.x < n_tiles) fetch_patch(t + gridDim.x);
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int s16 = 0; s16 < 14; ++s16) {
+      const int g = 2 * s16 + half;           // 8-element K group: (ky, pair j) = (g / 4, g % 4)
+      const unsigned char *ap = a_base + ((g >> 2) * kStemPC + (g & 3)) * GB;
+      const unsigned char *bp = b_base + g * GB;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap));
+      const bf16x8 bh0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp));
+      const bf16x8 bh1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 32 * WROW));
+      if constexpr (X3) {
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + 16));
+        const bf16x8 bl0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 16));
+        const bf16x8 bl1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 32 * WROW + 16));
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc[1], 0, 0, 0);
+      } else {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[1], 0, 0, 0);
+      }
+    }
+    // C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * half  ->  staging [pixel][channel]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        Cs[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * 68 + j * 32 + l31] = acc[j][e];
+    __syncthreads();
+    // 32 * WAVES pixels x 64 channels: thread -> (pixel tid / 2, 32 channels = 4 groups of 8)
+    {
+      const int px = tid >> 1, c0 = (tid & 1) * 32;
+      const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+      const bool ok = oy < ho && ox < wo;
+      const unsigned base = ok ? (unsigned)((oy * wo + ox) * OPX + (c0 / 8) * GB) : kInvalid;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(Cs + px * 68 + c0 + q * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(Cs + px * 68 + c0 + q * 8 + 4);
+        const f32x4 bb0 = *reinterpret_cast<const f32x4 *>(bias + c0 + q * 8);
+        const f32x4 bb1 = *reinterpret_cast<const f32x4 *>(bias + c0 + q * 8 + 4);
+        const float v[8] = {fmaxf(v0[0] + bb0[0], floor_), fmaxf(v0[1] + bb0[1], floor_), fmaxf(v0[2] + bb0[2], floor_),
+                            fmaxf(v0[3] + bb0[3], floor_), fmaxf(v1[0] + bb1[0], floor_), fmaxf(v1[1] + bb1[1], floor_),
+                            fmaxf(v1[2] + bb1[2], floor_), fmaxf(v1[3] + bb1[3], floor_)};
+        if constexpr (X3) {
+          u32x4 oh, ol;
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd) {
+            unsigned hw, lw;
+            split_pair(v[2 * wd], v[2 * wd + 1], &hw, &lw);
+            oh[wd] = hw;
+            ol[wd] = lw;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(oh, rsrcY, (int)(ok ? base + q * 32 : kInvalid), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(ol, rsrcY, (int)(ok ? base + q * 32 + 16 : kInvalid), 0, 0);
+        } else {
+          u32x4 o;
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd) o[wd] = pack_bf16(v[2 * wd], v[2 * wd + 1]);
+          __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(ok ? base + q * 16 : kInvalid), 0, 0);
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_stem_direct(const float *x, const float *w, const float *bias, float *y, int n, int hi, int wi, int kp,
+                              int relu, int prec, hipStream_t s) {
+  const int ho = (hi + 6 - 7) / 2 + 1, wo = (wi + 6 - 7) / 2 + 1;
+  if (!x || !w || !bias || !y || n <= 0 || hi <= 0 || wi <= 0 || kp < 224) return hipErrorInvalidValue;
+  if (prec != kPrecBf16 && prec != kPrecBf16x3) return hipErrorInvalidValue;
+  if ((double)hi * ((wi + 1) / 2) * 32.0 > 2.0e9 || (double)ho * wo * 256.0 > 2.0e9) return hipErrorInvalidValue;
+  const int th = prec == kPrecBf16 ? 8 : 16;
+  const long tiles = (long)n * ((ho + th - 1) / th) * ((wo + kStemTW - 1) / kStemTW);
+  // persistent workgroups: two per CU for bf16 (4 waves, 75 KB of LDS each), one per CU for split-bf16 (8 waves, 159 KB)
+  const long cap = prec == kPrecBf16 ? 512 : 256;
+  const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+  if (prec == kPrecBf16)
+    hipLaunchKernelGGL((stem_direct_kernel<false, 4>), dim3(grid), dim3(256), 0, s, x, w, bias, y, n, hi, wi, ho, wo, kp, relu);
+  else
+    hipLaunchKernelGGL((stem_direct_kernel<true, 8>), dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, kp, relu);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Split-K reduction (fp32): the segment sums of a ksplit launch are added in segment order -- the order the
 // unsplit kernel uses -- then bias, residual and ReLU exactly as in the conv epilogue.  4 channels per thread.
 // ---------------------------------------------------------------------------------------------
