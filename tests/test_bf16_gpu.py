@@ -120,3 +120,22 @@ def test_direct_stem_equals_the_generic_kernel_bitwise(hip_lib, monkeypatch, dty
             outs[flag, relu] = conv_bn_act_nhwc(x, w, *bn, stride=2, relu=relu, dtype=dtype).cpu()
     for relu in (True, False):
         assert torch.equal(outs['1', relu], outs['0', relu]), relu
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('h,w', [(224, 224), (96, 96), (64, 96), (90, 70), (256, 256)])
+def test_fused_stem_maxpool_equals_separate_kernels_bitwise(hip_lib, sd0, monkeypatch, dtype, h, w):
+    """Stem + max-pool in one kernel (7x8 pooled tiles over 15x17 conv tiles, -inf outside the image, the maximum taken
+    over the values the format would have stored) against the two separate kernels, through the engine: the pooled
+    'stem' tap and the logits must agree bit for bit, on sizes with ragged pooled tiles too."""
+    from workoutdetector_amd.engine import TsmEngine
+    x = make_input(70 + h, 2, 8, h, w)
+    got = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('TSM_STEM_POOL', flag)
+        eng = TsmEngine(height=h, width=w, max_clips=2, state_dict=sd0, dtype=dtype)
+        got[flag] = (eng.forward_tap(x, 'stem'), eng.run(None, {'input': x})[0], eng.forward_tap(x, 'conv1'))
+        eng.close()
+    assert np.array_equal(got['1'][0], got['0'][0]) and np.array_equal(got['1'][1], got['0'][1])
+    assert np.array_equal(got['1'][2], got['0'][2])        # the un-pooled tap still comes from the un-fused kernel
+    assert got['1'][0].shape == (16, (h // 2 + 1) // 2, (w // 2 + 1) // 2, 64)

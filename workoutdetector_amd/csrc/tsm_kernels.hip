@@ -1148,6 +1148,191 @@ __global__ void __launch_bounds__(64 * WAVES) stem_direct_kernel(const float *__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// stem_pool: stem_direct with the 3x3 stride-2 max-pool fused behind it (bf16 formats).  A workgroup of 8 waves owns
+// a 7 x 8 tile of POOLED pixels = the 15 x 17 conv outputs under it (255 of its 256 MFMA rows; 14 % more conv work
+// than the 224 an un-pooled tiling would spend) and the 35 x 20 pixel-pair input patch under those.  The conv tile
+// is staged in LDS as fp32 after bias / ReLU and the format's rounding (so that the maximum is taken over exactly the
+// values the separate max-pool kernel would read back), conv pixels outside the image are -inf, and 448 threads
+// reduce one 8-channel group of one pooled pixel each.  The stem's 112 x 112 x 64 output (the largest tensor of the
+// network) is never written or re-read.  Bit-identical to stem_direct + maxpool3x3s2.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPoolPH = 7, kPoolPW = 8;                              // pooled tile
+constexpr int kPoolCR = 2 * kPoolPH + 1, kPoolCC = 2 * kPoolPW + 1;  // conv tile 15 x 17
+constexpr int kPoolPR = 2 * kPoolCR + 5, kPoolPC = kPoolCC + 3;      // input patch 35 rows x 20 pixel pairs
+
+template <bool X3>
+__global__ void __launch_bounds__(512) stem_pool_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                        const float *__restrict__ bias, float *__restrict__ y, int n,
+                                                        int hi, int wi, int ho, int wo, int hp, int wp, int kp, int relu) {
+  constexpr int NT = 512;
+  constexpr int GB = X3 ? 32 : 16;
+  constexpr int WROW = X3 ? 1040 : 528;
+  constexpr int OPX = X3 ? 256 : 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * WROW + kPoolPR * kPoolPC * GB + 256 * 68 * 4];
+  unsigned char *Ws = smem;
+  unsigned char *Ps = smem + 64 * WROW;
+  float *Cs = reinterpret_cast<float *>(smem + 64 * WROW + kPoolPR * kPoolPC * GB);  // [256][68] fp32: the conv tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wpairs = (wi + 1) >> 1;
+
+  constexpr int WCH = 28 * GB / 16;
+  for (int c = tid; c < 64 * WCH; c += NT) {
+    const int row = c / WCH, ch = c - row * WCH;
+    *reinterpret_cast<u32x4 *>(Ws + row * WROW + ch * 16) = *reinterpret_cast<const u32x4 *>(
+        reinterpret_cast<const unsigned char *>(w) + (size_t)row * kp * (GB / 8) + ch * 16);
+  }
+  const unsigned x_frame = (unsigned)hi * wpairs * GB, y_frame = (unsigned)hp * wp * OPX;
+  const float floor_ = relu ? 0.f : -INFINITY;
+  const int tiles_x = (wp + kPoolPW - 1) / kPoolPW, tiles_y = (hp + kPoolPH - 1) / kPoolPH;
+  const long n_tiles = (long)n * tiles_y * tiles_x;
+
+  // MFMA row i of the workgroup = conv pixel (i / 17, i % 17) of the tile; row 255 repeats the last pixel
+  const int mi = wave * 32 + l31;
+  const int mr = (mi < kPoolCR * kPoolCC ? mi : kPoolCR * kPoolCC - 1) / kPoolCC;
+  const int mc = (mi < kPoolCR * kPoolCC ? mi : kPoolCR * kPoolCC - 1) - mr * kPoolCC;
+  const unsigned char *a_base = Ps + ((2 * mr) * kPoolPC + mc) * GB;
+  const unsigned char *b_base = Ws + l31 * WROW;
+
+  constexpr int PCH = kPoolPR * kPoolPC * GB / 16;
+  constexpr int PPASS = (PCH + NT - 1) / NT;
+  u32x4 pre[PPASS];
+  auto fetch_patch = [&](long t) {
+    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+    // conv tile origin (2*py0 - 1, 2*px0 - 1)  ->  input rows from 2*(2*py0 - 1) - 3, pairs from (2*px0 - 1) - 2
+    const int iy0 = 4 * ty * kPoolPH - 5, pc0 = 2 * tx * kPoolPW - 3;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(x) + (size_t)f * x_frame), 0, (int)x_frame, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q) {
+      const int ci = tid + q * NT;
+      const int g = X3 ? ci >> 1 : ci;
+      const int r = g / kPoolPC, c = g - r * kPoolPC;
+      const int iy = iy0 + r, pcx = pc0 + c;
+      const bool ok = ci < PCH && (unsigned)iy < (unsigned)hi && (unsigned)pcx < (unsigned)wpairs;
+      const unsigned off = (unsigned)((iy * wpairs + pcx) * GB + (X3 ? (ci & 1) * 16 : 0));
+      pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)(ok ? off : kInvalid), 0, 0);
+    }
+  };
+  if ((long)blockIdx.x < n_tiles) fetch_patch(blockIdx.x);
+  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+    const int py0 = ty * kPoolPH, px0 = tx * kPoolPW;
+    const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;   // conv pixel of tile position (0, 0)
+    const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(y) + (size_t)f * y_frame, 0, (int)y_frame, 0x00020000);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q)
+      if (tid + q * NT < PCH) *reinterpret_cast<u32x4 *>(Ps + (tid + q * NT) * 16) = pre[q];
+    if (t + gridDim.x < n_tiles) fetch_patch(t + gridDim.x);
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int s16 = 0; s16 < 14; ++s16) {
+      const int g = 2 * s16 + half;
+      const unsigned char *ap = a_base + ((g >> 2) * kPoolPC + (g & 3)) * GB;
+      const unsigned char *bp = b_base + g * GB;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap));
+      const bf16x8 bh0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp));
+      const bf16x8 bh1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 32 * WROW));
+      if constexpr (X3) {
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + 16));
+        const bf16x8 bl0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 16));
+        const bf16x8 bl1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 32 * WROW + 16));
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc[1], 0, 0, 0);
+      } else {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[1], 0, 0, 0);
+      }
+    }
+    // conv tile -> LDS as the values the format would hold: bias, ReLU, round (bf16) or split + re-sum (split-bf16);
+    // conv pixels outside the image become -inf so that they never win the maximum (max-pool padding)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float bcol = bias[j * 32 + l31];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int r = row / kPoolCC, c = row - r * kPoolCC;
+        const bool inside = row < kPoolCR * kPoolCC && (unsigned)(oy0 + r) < (unsigned)ho && (unsigned)(ox0 + c) < (unsigned)wo;
+        float v = fmaxf(acc[j][e] + bcol, floor_);
+        if constexpr (X3) {
+          unsigned hw, lw;
+          split_pair(v, 0.f, &hw, &lw);
+          v = __builtin_bit_cast(float, hw << 16) + __builtin_bit_cast(float, lw << 16);
+        } else {
+          v = __builtin_bit_cast(float, pack_bf16(v, 0.f) << 16);
+        }
+        Cs[row * 68 + j * 32 + l31] = inside ? v : -INFINITY;
+      }
+    }
+    __syncthreads();
+    if (tid < kPoolPH * kPoolPW * 8) {  // one 8-channel group of one pooled pixel per thread
+      const int pp = tid >> 3, cg = tid & 7;
+      const int pyl = pp / kPoolPW, pxl = pp - pyl * kPoolPW;
+      float m[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float *src = Cs + ((2 * pyl + ky) * kPoolCC + 2 * pxl + kx) * 68 + cg * 8;
+          const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+          m[0] = fmaxf(m[0], v0[0]); m[1] = fmaxf(m[1], v0[1]); m[2] = fmaxf(m[2], v0[2]); m[3] = fmaxf(m[3], v0[3]);
+          m[4] = fmaxf(m[4], v1[0]); m[5] = fmaxf(m[5], v1[1]); m[6] = fmaxf(m[6], v1[2]); m[7] = fmaxf(m[7], v1[3]);
+        }
+      const int py = py0 + pyl, px = px0 + pxl;
+      const bool ok = py < hp && px < wp;
+      const unsigned base = ok ? (unsigned)((py * wp + px) * OPX + cg * GB) : kInvalid;
+      if constexpr (X3) {
+        u32x4 oh, ol;
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+          unsigned hw, lw;
+          split_pair(m[2 * wd], m[2 * wd + 1], &hw, &lw);
+          oh[wd] = hw;
+          ol[wd] = lw;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(oh, rsrcY, (int)base, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(ol, rsrcY, (int)(ok ? base + 16 : kInvalid), 0, 0);
+      } else {
+        u32x4 o;
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) o[wd] = pack_bf16(m[2 * wd], m[2 * wd + 1]);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)base, 0, 0);
+      }
+    }
+  }
+}
+
+hipError_t launch_stem_pool(const float *x, const float *w, const float *bias, float *y, int n, int hi, int wi, int kp,
+                            int relu, int prec, hipStream_t s) {
+  const int ho = (hi + 6 - 7) / 2 + 1, wo = (wi + 6 - 7) / 2 + 1;
+  const int hp = (ho + 2 - 3) / 2 + 1, wp = (wo + 2 - 3) / 2 + 1;
+  if (!x || !w || !bias || !y || n <= 0 || hi <= 0 || wi <= 0 || kp < 224) return hipErrorInvalidValue;
+  if (prec != kPrecBf16 && prec != kPrecBf16x3) return hipErrorInvalidValue;
+  if ((double)hi * ((wi + 1) / 2) * 32.0 > 2.0e9) return hipErrorInvalidValue;
+  const long tiles = (long)n * ((hp + kPoolPH - 1) / kPoolPH) * ((wp + kPoolPW - 1) / kPoolPW);
+  const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);   // persistent, one 8-wave workgroup per CU
+  if (prec == kPrecBf16)
+    hipLaunchKernelGGL(stem_pool_kernel<false>, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
+  else
+    hipLaunchKernelGGL(stem_pool_kernel<true>, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
+  return hipGetLastError();
+}
+
 hipError_t launch_stem_direct(const float *x, const float *w, const float *bias, float *y, int n, int hi, int wi, int kp,
                               int relu, int prec, hipStream_t s) {
   const int ho = (hi + 6 - 7) / 2 + 1, wo = (wi + 6 - 7) / 2 + 1;
