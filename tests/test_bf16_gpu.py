@@ -122,7 +122,7 @@ def test_direct_stem_equals_the_generic_kernel_bitwise(hip_lib, monkeypatch, dty
         assert torch.equal(outs['1', relu], outs['0', relu]), relu
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3'])
+@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3', 'f32'])
 @pytest.mark.parametrize('h,w', [(224, 224), (96, 96), (64, 96), (90, 70), (256, 256)])
 def test_fused_stem_maxpool_equals_separate_kernels_bitwise(hip_lib, sd0, monkeypatch, dtype, h, w):
     """Stem + max-pool in one kernel (7x8 pooled tiles over 15x17 conv tiles, -inf outside the image, the maximum taken

@@ -510,8 +510,8 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     tsm::ConvParams p = make_params(e->convs[0], in4, nullptr, t1, n, cfg.height, cfg.width, true, 0, 1, prec);
     // bf16 formats: dedicated direct-conv stem (LDS-resident input patch), with the max-pool fused behind it unless
     // the un-pooled tensor itself is wanted; TSM_STEM_DIRECT=0 / TSM_STEM_POOL=0 fall back (all forms bit-identical)
-    const bool direct = prec != tsm::kPrecF32 && e->stem_direct;
-    if (direct && e->stem_pool && !want("conv1")) {
+    const bool direct = prec != tsm::kPrecF32 && e->stem_direct;   // (fp32 has the pool-fused direct form only)
+    if (e->stem_direct && e->stem_pool && !want("conv1")) {
       TSM_LAUNCH(e, s, tsm::launch_stem_pool(in4, e->convs[0].d_w, e->convs[0].d_b, cur, n, cfg.height, cfg.width,
                                               e->convs[0].kp, 1, prec, s));
       if (e->cur_timing) {  // keep the max-pool's launch slot: reported as "not recorded"

@@ -1317,16 +1317,136 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const float *__restrict_
   }
 }
 
+// fp32 form of stem_pool.  Input NHWC4 (one 16-byte group per pixel), weights [64][Kp] fp32 with K = (ky, kx, c4);
+// the conv tile's patch is 35 rows x 39 pixels.  MFMA sequence = conv_igemm's fp32 stem exactly: v_mfma_f32_32x32x2_f32
+// sums k = {4 * tap + s of lane-half 0, of lane-half 1}, taps taken in pairs (2g, 2g + 1), s = 0..3, g = 0..24, so
+// the results are bit-identical to it (tap 49 is K padding: zero weights, its A operand re-reads tap 48).
+constexpr int kPoolPCF = 2 * (kPoolCC - 1) + 7;   // 39 input pixels per patch row
+
+__global__ void __launch_bounds__(512) stem_pool_f32_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ y, int n,
+                                                            int hi, int wi, int ho, int wo, int hp, int wp, int kp,
+                                                            int relu) {
+  constexpr int NT = 512;
+  constexpr int WROW = 1040;                      // 200 used floats + padding: row stride = 4 dwords mod 64
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * WROW + kPoolPR * kPoolPCF * 16 + 256 * 68 * 4];
+  unsigned char *Ws = smem;
+  unsigned char *Ps = smem + 64 * WROW;
+  float *Cs = reinterpret_cast<float *>(smem + 64 * WROW + kPoolPR * kPoolPCF * 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  for (int c = tid; c < 64 * 50; c += NT) {       // 50 chunks of 16 B = taps 0..49 (tap 49 = zero padding)
+    const int row = c / 50, ch = c - row * 50;
+    *reinterpret_cast<f32x4 *>(Ws + row * WROW + ch * 16) = *reinterpret_cast<const f32x4 *>(w + (size_t)row * kp + ch * 4);
+  }
+  const unsigned x_frame = (unsigned)hi * wi * 16, y_frame = (unsigned)hp * wp * 256;
+  const float floor_ = relu ? 0.f : -INFINITY;
+  const int tiles_x = (wp + kPoolPW - 1) / kPoolPW, tiles_y = (hp + kPoolPH - 1) / kPoolPH;
+  const long n_tiles = (long)n * tiles_y * tiles_x;
+
+  const int mi = wave * 32 + l31;
+  const int mr = (mi < kPoolCR * kPoolCC ? mi : kPoolCR * kPoolCC - 1) / kPoolCC;
+  const int mc = (mi < kPoolCR * kPoolCC ? mi : kPoolCR * kPoolCC - 1) - mr * kPoolCC;
+  const unsigned char *a_base = Ps + ((2 * mr) * kPoolPCF + 2 * mc) * 16;
+  const unsigned char *b_base = Ws + l31 * WROW;
+
+  constexpr int PCH = kPoolPR * kPoolPCF;
+  constexpr int PPASS = (PCH + NT - 1) / NT;
+  u32x4 pre[PPASS];
+  auto fetch_patch = [&](long t) {
+    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+    const int iy0 = 4 * ty * kPoolPH - 5, ix0 = 4 * tx * kPoolPW - 5;   // 2 * (2 * p0 - 1) - 3
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(x) + (size_t)f * x_frame), 0, (int)x_frame, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q) {
+      const int ci = tid + q * NT;
+      const int r = ci / kPoolPCF, c = ci - r * kPoolPCF;
+      const int iy = iy0 + r, ix = ix0 + c;
+      const bool ok = ci < PCH && (unsigned)iy < (unsigned)hi && (unsigned)ix < (unsigned)wi;
+      pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)(ok ? (unsigned)((iy * wi + ix) * 16) : kInvalid), 0, 0);
+    }
+  };
+  if ((long)blockIdx.x < n_tiles) fetch_patch(blockIdx.x);
+  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+    const int py0 = ty * kPoolPH, px0 = tx * kPoolPW;
+    const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;
+    const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(y) + (size_t)f * y_frame, 0, (int)y_frame, 0x00020000);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q)
+      if (tid + q * NT < PCH) *reinterpret_cast<u32x4 *>(Ps + (tid + q * NT) * 16) = pre[q];
+    if (t + gridDim.x < n_tiles) fetch_patch(t + gridDim.x);
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 25; ++g) {
+      const int tap = 2 * g + half;                       // 0..49; 49 is K padding (zero weights)
+      const int tapa = tap < 49 ? tap : 48;               // its A operand must still be a finite number
+      const int ky = tapa / 7, kx = tapa - ky * 7;
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(a_base + (ky * kPoolPCF + kx) * 16);
+      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(b_base + tap * 16);
+      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(b_base + 32 * WROW + tap * 16);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b0[s4], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b1[s4], acc[1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float bcol = bias[j * 32 + l31];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int r = row / kPoolCC, c = row - r * kPoolCC;
+        const bool inside = row < kPoolCR * kPoolCC && (unsigned)(oy0 + r) < (unsigned)ho && (unsigned)(ox0 + c) < (unsigned)wo;
+        Cs[row * 68 + j * 32 + l31] = inside ? fmaxf(acc[j][e] + bcol, floor_) : -INFINITY;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                          // 56 pooled pixels x 16 channel quads = 896 items
+      const int item = tid + q * NT;
+      if (item < kPoolPH * kPoolPW * 16) {
+        const int pp = item >> 4, cq = item & 15;
+        const int pyl = pp / kPoolPW, pxl = pp - pyl * kPoolPW;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(Cs + ((2 * pyl + ky) * kPoolCC + 2 * pxl + kx) * 68 + cq * 4);
+            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+          }
+        const int py = py0 + pyl, px = px0 + pxl;
+        const bool ok = py < hp && px < wp;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), rsrcY,
+                                               (int)(ok ? (unsigned)((py * wp + px) * 256 + cq * 16) : kInvalid), 0, 0);
+      }
+    }
+  }
+}
+
 hipError_t launch_stem_pool(const float *x, const float *w, const float *bias, float *y, int n, int hi, int wi, int kp,
                             int relu, int prec, hipStream_t s) {
   const int ho = (hi + 6 - 7) / 2 + 1, wo = (wi + 6 - 7) / 2 + 1;
   const int hp = (ho + 2 - 3) / 2 + 1, wp = (wo + 2 - 3) / 2 + 1;
-  if (!x || !w || !bias || !y || n <= 0 || hi <= 0 || wi <= 0 || kp < 224) return hipErrorInvalidValue;
-  if (prec != kPrecBf16 && prec != kPrecBf16x3) return hipErrorInvalidValue;
-  if ((double)hi * ((wi + 1) / 2) * 32.0 > 2.0e9) return hipErrorInvalidValue;
+  if (!x || !w || !bias || !y || n <= 0 || hi <= 0 || wi <= 0 || kp < 200) return hipErrorInvalidValue;
+  if (prec != kPrecBf16 && prec != kPrecBf16x3 && prec != kPrecF32) return hipErrorInvalidValue;
+  if ((double)hi * wi * 16.0 > 2.0e9 || (prec != kPrecF32 && kp < 224)) return hipErrorInvalidValue;
   const long tiles = (long)n * ((hp + kPoolPH - 1) / kPoolPH) * ((wp + kPoolPW - 1) / kPoolPW);
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);   // persistent, one 8-wave workgroup per CU
-  if (prec == kPrecBf16)
+  if (prec == kPrecF32)
+    hipLaunchKernelGGL(stem_pool_f32_kernel, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
+  else if (prec == kPrecBf16)
     hipLaunchKernelGGL(stem_pool_kernel<false>, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
   else
     hipLaunchKernelGGL(stem_pool_kernel<true>, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
