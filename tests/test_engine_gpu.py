@@ -266,7 +266,8 @@ def test_warmup_tunes_every_bucket(hip_lib, sd0):
     eng = TsmEngine(height=64, width=64, max_clips=5, state_dict=sd0).warmup()
     for n in (1, 2, 4, 5):
         tiles = eng.conv_tiles(n)
-        assert tiles and all(v != 'heuristic' for k, v in tiles.items() if 'downsample' not in k), (n, tiles)
+        # (the stem runs on its own pool-fused kernel and the downsample convs inside the fused conv3: neither is tuned)
+        assert tiles and all(v != 'heuristic' for k, v in tiles.items() if 'downsample' not in k and k != 'conv1'), (n, tiles)
     eng.close()
 
 
