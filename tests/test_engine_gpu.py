@@ -215,6 +215,8 @@ def test_c_program_runs_a_forward(hip_lib, tmp_path):
     ('f32', 1, 8, 64, 64, 12, 1e-3),         # single-frame clips: both shifted channel groups read zeros
     ('bf16x3', 4, 8, 96, 64, 7, 1e-3),
     ('bf16', 2, 8, 64, 64, 12, 5e-2),
+    ('f32', 2, 8, 270, 480, 12, 1e-3),       # wide frames: many pooled tiles per row, ragged in both directions
+    ('bf16x3', 2, 8, 270, 480, 12, 1e-3),
 ])
 def test_unusual_configurations_against_oracle(hip_lib, dtype, t, div, h, w, ncls, rtol):
     """Segment counts, shift_div, class counts and aspect ratios other than the headline's, vs the CPU oracle."""
