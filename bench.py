@@ -10,7 +10,7 @@ every rank runs its own batch (weak scaling) and the only exchange is the RCCL a
 logits, which is inside the timed step.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant kernel is the conv_igemm<BM,BN,WGM,WGN,3,false,false,PREC,false,RKT> instantiation the engine's
+  roofline      the dominant kernel is the conv_igemm<BM,BN,WGM,WGN,3,false,false,PREC,false,SEG> instantiation the engine's
                 autotuner picked for the 3x3 convolutions of layer2..layer4 (13 launches per forward, one
                 third of the forward's time; if the tuner split them over two tile shapes, the shape with
                 the larger total).  Every one of
@@ -62,18 +62,24 @@ def host_cores():
 
 
 def measured_traffic(b, t, h, w, kernel):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json),
-    only when they were collected on this exact configuration; bench.py cannot run PMC passes itself."""
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json), only when
+    they were collected on this exact configuration AND on this exact kernel source (entries are stamped with the
+    sha of csrc/ they were measured on); bench.py cannot run PMC passes itself.  Returns (entry, stale_note)."""
+    from workoutdetector_amd.build import csrc_sha16
     try:
         d = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
     except (OSError, ValueError):
-        return None
+        return None, None
+    sha, stale = csrc_sha16(), None
     for e in d.get('entries', []):
         c = e.get('config', {})
         if ((c.get('clips_per_gpu'), c.get('num_segments'), c.get('height'), c.get('width')) == (b, t, h, w)
                 and e.get('kernel') == kernel):
-            return e
-    return None
+            if e.get('csrc_sha16') == sha:
+                return e, None
+            stale = (f"profiles/traffic.json holds {e.get('hbm_bytes_per_launch')} B/launch for this kernel measured on "
+                     f"csrc {e.get('csrc_sha16', 'unstamped (round 1)')}; current csrc is {sha}: re-run tools/pmc_traffic.sh")
+    return None, stale
 
 
 def cpu_baseline(sd_np, t, h, w, budget_s=15.0):
@@ -147,20 +153,32 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # TSM_BENCH_FORCE_COLLECTIVE=1 on ONE GPU: bring up a 1-rank nccl (RCCL) group and keep the all-gather inside the
+    # step, so that the exact code path of an N > 1 run (device_id= init, device-tensor collective) executes on a
+    # single-GPU box.  The number is still a 1-GPU number and says so in config.parallelism.
+    forced = world == 1 and os.environ.get('TSM_BENCH_FORCE_COLLECTIVE') == '1'
+    if world > 1 or forced:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if forced:
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if rehearsal:
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    collective = world > 1 or forced
+    backend = dist.get_backend() if collective else None
 
     from workoutdetector_amd.build import build_library
     if rank == 0:
         build_library()
-    if world > 1:
+    if collective:
         dist.barrier()
+    from workoutdetector_amd import distributed as tdist
     from workoutdetector_amd.distributed import all_gather_logits
     from workoutdetector_amd.engine import TsmEngine
+    tdist.set_force_collective(forced)
     from workoutdetector_amd.weights import make_state_dict
 
     T, H, W, B = args.segments, args.size, args.size, args.batch
@@ -177,22 +195,27 @@ def main():
 
         def step():
             eng.forward_device(clips, out=logits)
-            return all_gather_logits(logits) if world > 1 else logits
+            return all_gather_logits(logits) if collective else logits
 
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
         n_timed = min(args.steps, 64)
         if want_launch_times:
             eng.set_layer_timing(n_timed, only_conv3x3=True)   # HIP-event pairs around the dominant kernel's launches
+        # one event per step boundary on the stream the steps run on (torch's current stream is the stream handed to
+        # tsm_forward): per-step durations without a host sync inside the timed region
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record()
+        for i in range(args.steps):
             out = step()
+            marks[i + 1].record()
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -200,6 +223,7 @@ def main():
         # Per-launch durations of the timed forwards (events were recorded inside the timed region; reading
         # them here keeps the host syncs out of it).
         per_launch = [eng.layer_times_ms(i) for i in range(n_timed)] if want_launch_times else []
+        step_ms[dtype] = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         eng.set_layer_timing(0)
         # Whole-forward kernel time (one HIP-event pair around all launches of a forward), outside the
         # wall-clock region because reading it synchronises.
@@ -209,7 +233,7 @@ def main():
             fwd_ev_ms.append(eng.last_forward_ms)
         torch.cuda.synchronize()
         t_max = torch.tensor([elapsed], device='cuda')
-        if world > 1:
+        if collective:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
             # the exchange step on its own ("all-gather us"), outside the timed region
             torch.cuda.synchronize()
@@ -223,7 +247,7 @@ def main():
         eng.close()
         return float(t_max.item()), per_launch, sorted(fwd_ev_ms)[len(fwd_ev_ms) // 2], tiles
 
-    exchange_us = {}
+    exchange_us, step_ms = {}, {}
     elapsed, per_launch, fwd_ms, tiles = run_mode(args.dtype, True)
     alt = None
     if not args.no_alt:
@@ -249,10 +273,10 @@ def main():
             groups.setdefault(tiles[r['name']], []).extend(d[r['name']] for d in per_launch)
         dom_tile, dom_ms = max(groups.items(), key=lambda kv: sum(kv[1]))
         prec_id = {'f32': 0, 'bf16x3': 1, 'bf16': 2}[args.dtype]
-        main_tile = dom_tile.split('+')[0]
+        main_tile = dom_tile.split('/')[0]
         waves = '1, 1' if main_tile == '32x32' else '4, 2' if main_tile.endswith('w8') else '2, 2'
-        # template arguments: BM, BN, WGM, WGN, KS, SHIFT, RES, PREC, DUAL, RKT, SEG (fp32 long-K layers accumulate K in segments)
-        dom_kernel = 'conv_igemm<%s, %s, 3, false, false, %d, false, 1, %s>' % (
+        # template arguments: BM, BN, WGM, WGN, KS, SHIFT, RES, PREC, DUAL, SEG (fp32 long-K layers accumulate K in segments)
+        dom_kernel = 'conv_igemm<%s, %s, 3, false, false, %d, false, %s>' % (
             main_tile.replace('w8', '').replace('x', ', '), waves, prec_id, 'true' if args.dtype == 'f32' else 'false')
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         peak_name = ('dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); the kernel executes 3 MFMA FLOPs per algorithmic FLOP'
@@ -260,25 +284,39 @@ def main():
                      else 'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), dense')
         dom_avg_ms = sum(dom_ms) / len(dom_ms)
         achieved = dom_gflop / dom_avg_ms
-        traffic_entry = measured_traffic(B, T, H, W, dom_kernel)
+        traffic_entry, traffic_stale = measured_traffic(B, T, H, W, dom_kernel)
+        sm = step_ms[args.dtype]
+        if rehearsal:
+            parallelism = (f'REHEARSAL: {world} ranks sharing cuda:0, gloo all-gather through host memory -- control flow '
+                           'only, not a measurement')
+        elif world > 1:
+            parallelism = f'clip-sharded x{world}, RCCL (nccl backend) all-gather of logits'
+        elif forced:
+            parallelism = 'single GPU; 1-rank RCCL (nccl backend) group, all-gather of logits kept inside the step'
+        else:
+            parallelism = 'single GPU'
         line = {
-            'metric': f'clips/sec ({T}x3x{H}x{W} TSM-R50)', 'value': round(value, 2), 'unit': 'clips/s',
+            'metric': f'clips/sec ({T}x3x{H}x{W} TSM-R50)', 'value': None if rehearsal else round(value, 2),
+            'unit': 'clips/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+            'step_ms': {'min': round(sm[0], 4), 'median': round(sm[len(sm) // 2], 4), 'max': round(sm[-1], 4),
+                        'note': 'rank-0 per-step durations between HIP events on the step stream: the noise floor '
+                                'design decisions must be read against'},
+            'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'TSM-R50 {T}-seg {H}x{W} 12-class inference, batch {B} clips per GPU, ' +
                                    '%s NHWC, device-resident input (BASELINE.json configs[%d])' % (args.dtype, 4 if args.config == 5 else 1),
                        'clips_per_gpu': B, 'num_segments': T, 'height': H, 'width': W, 'num_class': 12,
                        'weights': 'seeded random init (no trained weights offline)',
-                       'parallelism': f'clip-sharded x{world}, RCCL all-gather of logits' if world > 1 else 'single GPU'},
+                       'parallelism': parallelism},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                          'traffic': (traffic_entry or {}).get('hbm_bytes_per_launch'),
+                         **({'traffic_stale': traffic_stale} if traffic_stale else {}),
                          'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/traffic.json)',
-                         'kernel': dom_kernel + ' (3x3 convs of layer2-4, %d of 13 launches per forward%s)'
-                                   % (len(dom_ms) // len(per_launch),
-                                      '; tail rows on single-wave 32x32 tiles of the same kernel, overlapped on a '
-                                      'second stream and inside the timed launch' if '+' in dom_tile else ''),
+                         'kernel': dom_kernel + ' (3x3 convs of layer2-4, %d of 13 launches per forward)'
+                                   % (len(dom_ms) // len(per_launch)),
                          'gflop_per_launch': round(dom_gflop, 3), 'avg_launch_ms': round(dom_avg_ms, 4),
                          'launches_timed': len(dom_ms),
                          'peak_name': peak_name,
@@ -292,8 +330,11 @@ def main():
             gbs = traffic_entry['forward_hbm_bytes'] / 1e9 / (fwd_ms / 1e3)
             line['roofline'].update({'forward_hbm_gbs': round(gbs, 1), 'forward_hbm_frac': round(gbs / PEAK_HBM_GBS, 4),
                                      'hbm_peak_gbs': PEAK_HBM_GBS})
-        if world > 1:
-            line['exchange'] = {'collective': 'all_gather_into_tensor of f32[%d, 12] per rank (RCCL)' % B,
+        if rehearsal:
+            line['rehearsal'] = True
+        if collective:
+            line['exchange'] = {'collective': 'all_gather_into_tensor of f32[%d, 12] per rank (backend %s%s)'
+                                              % (B, backend, ' = RCCL' if backend == 'nccl' else ': NOT RCCL, rehearsal'),
                                 'avg_us': round(exchange_us[args.dtype], 1),
                                 'note': 'back-to-back latency of the only data-path collective, measured outside the timed steps'}
         if alt is not None:
@@ -310,7 +351,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, T, H, W)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

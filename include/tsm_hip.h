@@ -142,11 +142,12 @@ float tsm_last_forward_ms(tsm_engine *e);
 int tsm_set_layer_timing(tsm_engine *e, int32_t n_forwards, int32_t only_conv3x3);
 int tsm_layer_times(tsm_engine *e, int32_t forward_index, float *ms_out, int32_t cap, int32_t *n_out);
 
-/* Conv tile shape the engine's autotuner chose for each conv launch of an `n_clips` forward, in launch
- * order (stem, then per block [downsample,] conv1, conv2, conv3), as `main + 16 * tail`: 1 = 128x128,
- * 2 = 128x64, 3 = 64x64, 4 = 32x32 (one wave), 0 = not tuned (heuristic); tail != 0 means the rows that do
- * not fill whole rounds of the chip with `main` tiles run on `tail` tiles on a second stream.  The first tsm_forward with a new n_clips times every valid shape per
- * layer once (results are bit-identical across shapes); TSM_AUTOTUNE=0 in the environment disables it. */
+/* Conv tile code the engine's autotuner chose for each conv launch of an `n_clips` forward, in launch order (stem,
+ * then per block [downsample,] conv1, conv2, conv3): 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x32 (one wave),
+ * 5 = 128x128 on 8 waves, 0 = not tuned (heuristic); + 256 = split-K form of a segmented fp32 layer (one workgroup per
+ * tile and K segment, combined in segment order).  The first tsm_forward with a new power-of-two bucket of n_clips
+ * times every valid code per layer once (results are bit-identical across codes); TSM_AUTOTUNE=0 in the environment
+ * at tsm_create disables it.  Every TSM_* environment variable is read once, in tsm_create. */
 int tsm_conv_tiles(tsm_engine *e, int32_t n_clips, int32_t *tiles_out, int32_t cap, int32_t *n_out);
 
 /* Per-op entry points (device pointers; used by the parity tests and as building blocks) ----- */

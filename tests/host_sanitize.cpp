@@ -1,0 +1,123 @@
+// ASAN + UBSAN harness for the pure-host pieces of the engine (workoutdetector_amd/csrc/tsm_host_util.h): built by
+// tests/test_host_sanitizers.py with  g++ -fsanitize=address,undefined -fno-sanitize-recover=all  and run on the CPU.
+// (GPU AddressSanitizer is not available on this pool; the device code is covered by the parity tests instead.)
+//
+//   1. fuzz loop over malformed TSM_TUNE_CACHE lines through parse_tune_line (the hand-written parser that reads
+//      a user-supplied file): truncated lines, huge numbers, stray bytes, missing separators, wrong code counts.
+//   2. fold_and_pack / fold_and_pack_stem_pairs / to_split / to_bf16 on ragged sizes, with the packed-buffer
+//      invariants checked (every weight lands inside [cout][kp], padding stays zero, split hi+lo == value to 2^-16).
+#include <cstdio>
+#include <random>
+
+#include "../workoutdetector_amd/csrc/tsm_host_util.h"
+
+using namespace tsm_host;
+
+static int failures = 0;
+#define EXPECT(cond)                                                      \
+  do {                                                                    \
+    if (!(cond)) {                                                        \
+      std::fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      ++failures;                                                         \
+    }                                                                     \
+  } while (0)
+
+static void fuzz_tune_lines(unsigned seed, int rounds) {
+  std::mt19937 rng(seed);
+  const std::string want = "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|";
+  const int kNumTiles = 6;
+  // a well-formed line first
+  {
+    std::vector<int> codes(5, -1);
+    const std::string line = want + "3,259,4,1,5\n";
+    EXPECT(parse_tune_line(line.c_str(), want, kNumTiles, &codes));
+    EXPECT(codes[0] == 3 && codes[1] == 259 && codes[2] == 4 && codes[3] == 1 && codes[4] == 5);
+  }
+  const char *bad[] = {"", "\n", "|", "abi3", "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|",
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3",            // too few
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,3,3",        // too many
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,9",          // tile out of range
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,35",         // reserved bits set
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,-1",
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,99999999999999999999999999",
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,,3,3,3",
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3 3 3 3 3",
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|9999,abc",
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|128|3,3,3,3,3"};        // another bucket
+  for (const char *b : bad) {
+    std::vector<int> codes(5, -7);
+    EXPECT(!parse_tune_line(b, want, kNumTiles, &codes));
+    for (int c : codes) EXPECT(c == -7);   // untouched on failure
+  }
+  // random mutations of a good line and random byte strings
+  const std::string good = want + "3,259,4,1,5\n";
+  for (int r = 0; r < rounds; ++r) {
+    std::string line = (rng() & 1) ? good : std::string();
+    const int edits = 1 + (int)(rng() % 8);
+    for (int k = 0; k < edits; ++k) {
+      const int op = (int)(rng() % 4);
+      const size_t pos = line.empty() ? 0 : rng() % (line.size() + 1);
+      if (op == 0 || line.empty()) line.insert(pos, 1, (char)(1 + rng() % 255));
+      else if (op == 1) line.erase(pos < line.size() ? pos : line.size() - 1, 1 + rng() % 4);
+      else if (op == 2) line[pos < line.size() ? pos : line.size() - 1] = (char)(1 + rng() % 255);
+      else line.insert(pos, "0123456789,|-\n"[rng() % 14] == 0 ? "" : std::string(1 + rng() % 30, "0123456789,|-\n"[rng() % 14]));
+    }
+    if (line.size() > 4000) line.resize(4000);
+    std::vector<int> codes(5, -7);
+    const bool ok = parse_tune_line(line.c_str(), want, kNumTiles, &codes);
+    for (int c : codes) EXPECT(ok ? (c >= 0 && (c & ~0x10F) == 0 && (c & 15) < kNumTiles) : c == -7);
+  }
+}
+
+static void check_packing(unsigned seed) {
+  std::mt19937 rng(seed);
+  std::uniform_real_distribution<float> uni(-2.f, 2.f);
+  const int cases[][4] = {{64, 64, 1, 64}, {64, 64, 3, 576}, {128, 256, 1, 256}, {64, 3, 7, 224}, {96, 32, 3, 320}};
+  for (const auto &c : cases) {
+    const int cout = c[0], cin = c[1], k = c[2], kp = c[3], cp = k == 7 ? 4 : cin;
+    std::vector<float> w((size_t)cout * cin * k * k), g(cout), b(cout), m(cout), v(cout), wp, bias;
+    for (float &x : w) x = uni(rng);
+    for (int o = 0; o < cout; ++o) { g[o] = 1.f + 0.25f * uni(rng); b[o] = uni(rng); m[o] = uni(rng); v[o] = 0.5f + std::fabs(uni(rng)); }
+    fold_and_pack(w.data(), g.data(), b.data(), m.data(), v.data(), cout, cin, k, cp, kp, &wp, &bias);
+    EXPECT(wp.size() == (size_t)cout * kp && (int)bias.size() == cout);
+    const float s0 = g[0] / std::sqrt(v[0] + kBnEps);
+    EXPECT(wp[0] == w[0] * s0);                                  // (o=0, ky=0, kx=0, c=0)
+    for (int kk = k * k * cp; kk < kp; ++kk) EXPECT(wp[kk] == 0.f);  // K padding of row 0 stays zero
+    std::vector<float> split = wp, half = wp;
+    to_split(&split);
+    EXPECT(split.size() == wp.size());
+    const uint16_t *sp = reinterpret_cast<const uint16_t *>(split.data());
+    for (size_t i = 0; i + 8 <= wp.size(); i += 8)
+      for (int e = 0; e < 8; ++e) {
+        const float back = bf2f(sp[2 * i + e]) + bf2f(sp[2 * i + 8 + e]);
+        EXPECT(std::fabs(back - wp[i + e]) <= std::ldexp(std::fabs(wp[i + e]), -15) + 1e-30f);
+      }
+    to_bf16(&half);
+    EXPECT(half.size() == (wp.size() + 1) / 2);
+    if (k == 7) {
+      std::vector<float> wq, bq;
+      fold_and_pack_stem_pairs(w.data(), g.data(), b.data(), m.data(), v.data(), cout, 224, &wq, &bq);
+      EXPECT(wq.size() == (size_t)cout * 224);
+      EXPECT(wq[0] == 0.f);                                      // (ky 0, pair 0, pixel 0) = kx -1: zero weight
+      EXPECT(wq[4] == w[0] * s0);                                // (ky 0, pair 0, pixel 1, c 0) = kx 0
+      for (size_t i = 3; i < wq.size(); i += 4) EXPECT(wq[i] == 0.f);   // channel 3 is padding everywhere
+    }
+  }
+  // NaN / inf survive the bf16 conversion as NaN / inf (never as a finite number)
+  EXPECT(std::isnan(bf2f(f2bf(std::nanf("")))));
+  EXPECT(std::isinf(bf2f(f2bf(INFINITY))));
+  EXPECT(segment_len(4608, 0) > 0 && segment_len(4608, 1) == 0 && segment_len(512, 0) == 0);
+  EXPECT(tile_bucket(1) == 1 && tile_bucket(5) == 8 && tile_bucket(32) == 32 && tile_bucket(33) == 64);
+}
+
+int main(int argc, char **argv) {
+  const int rounds = argc > 1 ? std::atoi(argv[1]) : 20000;
+  fuzz_tune_lines(1234, rounds);
+  check_packing(99);
+  if (failures) {
+    std::fprintf(stderr, "%d failures\n", failures);
+    return 1;
+  }
+  std::printf("host sanitize ok (%d fuzz rounds)\n", rounds);
+  return 0;
+}

@@ -92,3 +92,31 @@ def test_eval_count_property():
     assert mae == pytest.approx(np.mean([1 / v for v in gt.values()]))
     assert (mae, obo) == counting_oracle.eval_count(pred, gt)
     assert eval_count({'a': 4}, {'a': 0}) == (0.0, 0.0)
+
+
+def test_analyze_count_is_the_reference_drop_in(golden_dir, tmp_path, capsys):
+    """utils/eval.py:58-114 executed on synthetic evaluation CSVs (tests/golden/make_reference_vectors.py): same
+    signature (csv, out_csv), same output CSV text (columns action,split,mae,obo_acc,total,avg_count; OBO as a count;
+    per-split 'all' rows with the int(mae * n) re-accumulation) and the same printout."""
+    import inspect
+    import json
+
+    from workoutdetector_amd import eval as tsm_eval
+    assert list(inspect.signature(tsm_eval.analyze_count).parameters) == ['csv', 'out_csv']
+    ref = json.load(open(f'{golden_dir}/ref_analyze_count.json'))
+    assert len(ref['cases']) >= 4
+    for i, case in enumerate(ref['cases']):
+        src, dst = tmp_path / f'in{i}.csv', tmp_path / f'out{i}.csv'
+        src.write_text(case['in_csv'])
+        capsys.readouterr()
+        assert tsm_eval.analyze_count(str(src), str(dst)) is None
+        assert dst.read_text() == case['out_csv'], i
+        assert capsys.readouterr().out == case['stdout'], i
+    tsm_eval.analyze_count(str(tmp_path / 'in0.csv'), None)          # out_csv=None: print only
+    # a (split, action) pair without videos divides by zero in the reference's obo_mae; same here
+    import pandas as pd
+    df = pd.read_csv(tmp_path / 'in1.csv', index_col=0)
+    df = df[~((df.split == 'val') & (df.action == 'squat'))]
+    df.to_csv(tmp_path / 'hole.csv')
+    with pytest.raises(ZeroDivisionError):
+        tsm_eval.analyze_count(str(tmp_path / 'hole.csv'), None)

@@ -63,7 +63,7 @@ def test_all_gather_of_ragged_clip_logits(tmp_path):
 def _dataset_worker(rank, world, root, out_dir):
     from tests._stub import StubModel
     from workoutdetector_amd import inference_count as ic
-    ic.inference_dataset(StubModel(), ['test'], out_dir, checkpoint='stub', data_root=root, batch_clips=3)
+    ic.inference_dataset(StubModel(), ['test'], out_dir, checkpoint='stub', data_root=root, batch_clips=3, shard='clips')
 
 
 def test_sharded_inference_dataset_equals_single_process(tmp_path, golden_dir):

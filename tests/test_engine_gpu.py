@@ -179,26 +179,6 @@ def test_create_model_from_checkpoint_and_onnx(hip_lib, sd0, tmp_path):
     m.close()
 
 
-def test_fp32_pipeline_variants_are_bit_identical(hip_lib, sd0, monkeypatch):
-    """TSM_CONV_RK selects the fp32 64x64 pipeline (two LDS buffers / register-resident K-step / the same fed by
-    LDS-DMA with an XOR-swizzled image).  Same k order in all three, so logits and taps must match bit for bit."""
-    from workoutdetector_amd.engine import TsmEngine
-    x = make_input(31, 2, 8, 96, 96)
-    monkeypatch.setenv('TSM_AUTOTUNE', '0')
-    monkeypatch.setenv('TSM_CONV_TILE', '64x64')
-    outs, taps = {}, {}
-    for rk in ('0', '1', '2'):
-        monkeypatch.setenv('TSM_CONV_RK', rk)
-        eng = TsmEngine(height=96, width=96, max_clips=2, state_dict=sd0)
-        outs[rk] = eng.run(None, {'input': x})[0]
-        taps[rk] = eng.forward_tap(x, 'layer2.0')
-        eng.close()
-    assert np.array_equal(outs['0'], outs['1']) and np.array_equal(outs['0'], outs['2'])
-    assert np.array_equal(taps['0'], taps['1']) and np.array_equal(taps['0'], taps['2'])
-    want = tsm_oracle.tsm_forward(sd0, torch.from_numpy(x)).numpy()
-    assert_close(outs['2'], want, rtol=1e-3, atol_scale=1e-4, what='dma variant vs oracle')
-
-
 def test_c_program_runs_a_forward(hip_lib, tmp_path):
     """The engine driven from plain C (tests/abi_c_smoke.c): all-zero convs -> logits == fc.bias exactly."""
     import subprocess
@@ -236,17 +216,15 @@ def test_unusual_configurations_against_oracle(hip_lib, dtype, t, div, h, w, ncl
 def test_split_k_is_bitwise_identical_to_whole_k(hip_lib, sd0, monkeypatch):
     """Long-K fp32 layers accumulate K in fixed segments (ConvParams::kseg_len), so the split-K launch form (one
     workgroup per tile and segment + ordered reduction, what the tuner picks at small batch) must reproduce the
-    whole-K form bit for bit, on both tile shapes that implement it and in all three fp32 pipelines."""
+    whole-K form bit for bit, on both tile shapes that implement it."""
     from workoutdetector_amd.engine import TsmEngine
     x = make_input(31, 2, 8, 96, 96)
     outs = {}
     for name, env in [('whole 64x64', {'TSM_AUTOTUNE': '1', 'TSM_CONV_CODE': '3'}),
                       ('split 64x64', {'TSM_AUTOTUNE': '1', 'TSM_CONV_CODE': str(0x100 | 3)}),
                       ('split 32x32', {'TSM_AUTOTUNE': '1', 'TSM_CONV_CODE': str(0x100 | 4)}),
-                      ('split 64x64, two LDS buffers', {'TSM_AUTOTUNE': '1', 'TSM_CONV_CODE': str(0x100 | 3), 'TSM_CONV_RK': '0'}),
-                      ('split 64x64, LDS-DMA', {'TSM_AUTOTUNE': '1', 'TSM_CONV_CODE': str(0x100 | 3), 'TSM_CONV_RK': '2'}),
                       ('tuned', {})]:
-        for k in ('TSM_AUTOTUNE', 'TSM_CONV_CODE', 'TSM_CONV_RK'):
+        for k in ('TSM_AUTOTUNE', 'TSM_CONV_CODE'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

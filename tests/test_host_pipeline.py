@@ -112,7 +112,12 @@ def test_inference_dataset_schema_and_eval(tiny_dataset, tmp_path):
     assert len(df) == 3 and set(df['action']) <= {'pull_up', 'squat', 'situp', 'push_up', 'jump_jack', 'front_raise'}
     want = counting_oracle.obo_mae(list(df['pred_count']), list(df['gt_count']))
     assert (mae, obo) == want
-    assert len(tsm_eval.analyze_count(df)) >= 1
+    assert len(tsm_eval.summarize_counts(df)) >= 1
+    # analyze_count(csv, out_csv): the reference's signature; action 'all' rows close every split
+    tsm_eval.analyze_count(str(tmp_path / 'eval.csv'), str(tmp_path / 'eval_meta.csv'))
+    meta = pd.read_csv(tmp_path / 'eval_meta.csv', index_col=0)
+    assert list(meta.columns) == ['action', 'split', 'mae', 'obo_acc', 'total', 'avg_count']
+    assert int(meta[meta.action == 'all'].total.sum()) == 3
 
 
 def test_streaming_counter_matches_offline(tmp_path):

@@ -31,6 +31,23 @@ def test_remap_checkpoint_keys_like_create_model():
     assert 'fc.weight' not in out and 'new_fc.weight' not in out
 
 
+def test_remap_reproduces_the_executed_reference_block(golden_dir):
+    """tests/golden/ref_ckpt_remap.json: key lists pushed through the reference's own remap statements
+    (models/tsm.py:451-473, AST-extracted and executed by make_reference_vectors.py).  Same keys, same order, same
+    source tensor behind every key -- module./model. prefixes, new_fc -> fc, classifier of the wrong row count dropped,
+    and the reference's delete-after-copy of a classifier already named module.fc."""
+    import json
+    ref = json.load(open(f'{golden_dir}/ref_ckpt_remap.json'))
+    assert len(ref['cases']) >= 6
+    for case in ref['cases']:
+        fc = case['keys'][-2]
+        sd = {k: torch.zeros(case['fc_rows'] if k == fc else 1, 3) + i for i, k in enumerate(case['keys'])}
+        src_of = {id(v): k for k, v in sd.items()}
+        out = remap_checkpoint_keys(sd, case['num_class'])
+        assert [[k, src_of[id(v)]] for k, v in out.items()] == case['remapped'], case['name']
+        assert list(sd) == case['keys']                   # the caller's dict is not modified
+
+
 def _to_mmaction(sd):
     """Inverse mapping, written independently: engine keys -> mmaction2 ResNetTSM / TSMHead names."""
     out = {}

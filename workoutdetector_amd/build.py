@@ -34,6 +34,20 @@ def _deps() -> List[str]:
     return deps
 
 
+def csrc_sha16() -> str:
+    """First 16 hex digits of the sha256 over the kernel / engine sources (file names and contents, sorted): stamps
+    measurements that depend on the exact kernel code (profiles/traffic.json), so that bench.py can tell a PMC figure
+    measured on this source from a stale one."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith(('.hip', '.h')):
+            h.update(name.encode())
+            with open(os.path.join(CSRC, name), 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

@@ -18,15 +18,19 @@
 #include <vector>
 
 #include "../../include/tsm_hip.h"
+#include "tsm_host_util.h"
 #include "tsm_kernels.h"
 
 namespace {
 
-constexpr float kBnEps = 1e-5f;
+using namespace tsm_host;
+
 constexpr int kBlocks[4] = {3, 4, 6, 3};
 constexpr int kPlanes[4] = {64, 128, 256, 512};
 
-std::string g_create_error;
+// Message of the last failure of an engine-less entry point (tsm_create, the per-op functions): per calling thread, so
+// two threads driving two engines never write the same string (include/tsm_hip.h, "no global state").
+thread_local std::string g_create_error;
 
 struct HostTensor {
   std::vector<float> data;
@@ -42,17 +46,6 @@ struct ConvLayer {
   float *d_w = nullptr, *d_b = nullptr;
 };
 
-// Long-K fp32 layers accumulate K in segments of ~16 K-steps (512 channels-taps) so that they can also run
-// split-K (one workgroup per tile and segment) with bit-identical results when the batch is too small to
-// fill the chip with whole-K tiles.  The choice depends on the layer only, never on the batch size.
-int segment_len(int kp, int prec) {
-  if (prec != tsm::kPrecF32) return 0;
-  const int nk = kp / 32;
-  if (nk < 32) return 0;
-  const int nseg = nk / 16;
-  return (nk + nseg - 1) / nseg;
-}
-
 struct Block {
   int conv1, conv2, conv3, down;  // indices into convs, down = -1 if none
   int stride;
@@ -66,78 +59,6 @@ int ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
   return l;
-}
-
-int round_up(int v, int m) { return (v + m - 1) / m * m; }
-
-uint16_t f2bf(float f) {  // round to nearest even, like v_cvt_pk_bf16_f32
-  uint32_t u;
-  std::memcpy(&u, &f, 4);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-float bf2f(uint16_t h) {
-  const uint32_t u = (uint32_t)h << 16;
-  float f;
-  std::memcpy(&f, &u, 4);
-  return f;
-}
-// fp32 -> bf16, two elements per float slot (the vector shrinks to half its length).
-void to_bf16(std::vector<float> *v) {
-  std::vector<float> out((v->size() + 1) / 2, 0.f);
-  uint16_t *o = reinterpret_cast<uint16_t *>(out.data());
-  for (size_t i = 0; i < v->size(); ++i) o[i] = f2bf((*v)[i]);
-  v->swap(out);
-}
-// In place: every group of 8 consecutive floats becomes [hi x8 | lo x8] bf16 (32 bytes, same size).
-void to_split(std::vector<float> *v) {
-  uint16_t g[16];
-  for (size_t i = 0; i + 8 <= v->size(); i += 8) {
-    for (int e = 0; e < 8; ++e) {
-      const float x = (*v)[i + e];
-      g[e] = f2bf(x);
-      g[8 + e] = f2bf(x - bf2f(g[e]));
-    }
-    std::memcpy(v->data() + i, g, 32);
-  }
-}
-
-// Stem weights for the bf16 formats, whose input is stored as pixel pairs (tsm_kernels.hip, pack_input_kernel):
-// K = (ky, pair j, pixel-in-pair q, c4) = 7 x 4 x 2 x 4 = 224, covering pixels 2ox-4 .. 2ox+3, i.e. kx = 2j + q - 1
-// (kx = -1 and c = 3 carry zero weights).
-void fold_and_pack_stem_pairs(const float *w, const float *gamma, const float *beta, const float *mean,
-                              const float *var, int cout, int kp, std::vector<float> *wp, std::vector<float> *bias) {
-  wp->assign((size_t)cout * kp, 0.f);
-  bias->resize(cout);
-  for (int o = 0; o < cout; ++o) {
-    const float scale = gamma[o] / std::sqrt(var[o] + kBnEps);
-    (*bias)[o] = beta[o] - mean[o] * scale;
-    float *dst = wp->data() + (size_t)o * kp;
-    for (int c = 0; c < 3; ++c)
-      for (int ky = 0; ky < 7; ++ky)
-        for (int kx = 0; kx < 7; ++kx) {
-          const int j = (kx + 1) >> 1, q = (kx + 1) & 1;
-          dst[((ky * 4 + j) * 2 + q) * 4 + c] = w[(((size_t)o * 3 + c) * 7 + ky) * 7 + kx] * scale;
-        }
-  }
-}
-
-// Fold BN into the conv and pack OIHW -> [Cout][Kp], K = (ky, kx, c) with c padded to cp.
-void fold_and_pack(const float *w, const float *gamma, const float *beta, const float *mean,
-                   const float *var, int cout, int cin, int k, int cp, int kp, std::vector<float> *wp,
-                   std::vector<float> *bias) {
-  wp->assign((size_t)cout * kp, 0.f);
-  bias->resize(cout);
-  for (int o = 0; o < cout; ++o) {
-    const float scale = gamma[o] / std::sqrt(var[o] + kBnEps);
-    (*bias)[o] = beta[o] - mean[o] * scale;
-    float *dst = wp->data() + (size_t)o * kp;
-    for (int c = 0; c < cin; ++c)
-      for (int ky = 0; ky < k; ++ky)
-        for (int kx = 0; kx < k; ++kx)
-          dst[(ky * k + kx) * cp + c] = w[(((size_t)o * cin + c) * k + ky) * k + kx] * scale;
-  }
 }
 
 }  // namespace
@@ -173,12 +94,12 @@ struct tsm_engine {
   bool stem_direct = true;  // TSM_STEM_DIRECT=0: bf16-format stems on the generic implicit-GEMM kernel (bit-identical, slower)
   // TSM_TUNE_CACHE=<file>: tuned tile codes are appended to / read from this file, one line per bucket, keyed by
   // `tune_sig` (ABI, device name, geometry, dtype): a later process skips the timing pass.  Codes never change
-  // results, so a stale or foreign line can only cost speed; malformed lines are ignored.
+  // results and every code is re-validated against its layer at launch (run_forward, code_ok), so a stale, foreign
+  // or hand-edited line can only cost speed; malformed lines are ignored.
   std::string tune_path, tune_sig;
-  // tail launches: fine (32x32, one wave) tiles for the rows the coarse tiles cannot spread evenly over the
-  // CUs, issued on a second stream so that they overlap the coarse launch
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // Tuning hooks, read ONCE in tsm_create (never per launch): TSM_CONV_TILE=<name> forces one tile shape wherever it
+  // is valid, TSM_CONV_CODE=<int> one tile code (tile | 0x100 = split-K form); tests and tools/ sweeps only.
+  int force_tile = 0, force_code = -1;
   int n_cu = 256;
   int timing_left = 0;
   bool timing_only3x3 = false;
@@ -294,14 +215,6 @@ tsm::ConvParams make_params(const ConvLayer &c, const float *x, const float *res
   return p;
 }
 
-// Tuned tile shapes are cached per power-of-two bucket of the clip count (ragged last batches of a video
-// would otherwise each pay a tuning pass): the first clip count that lands in a bucket tunes it.
-int tile_bucket(int n_clips) {
-  int b = 1;
-  while (b < n_clips) b <<= 1;
-  return b;
-}
-
 bool tune_cache_load(tsm_engine *e, int key, std::vector<int> *codes) {
   if (e->tune_path.empty()) return false;
   FILE *f = fopen(e->tune_path.c_str(), "r");
@@ -309,24 +222,7 @@ bool tune_cache_load(tsm_engine *e, int key, std::vector<int> *codes) {
   const std::string want = e->tune_sig + "|" + std::to_string(key) + "|";
   char line[4096];
   bool ok = false;
-  while (!ok && fgets(line, sizeof line, f)) {
-    if (strncmp(line, want.c_str(), want.size()) != 0) continue;
-    std::vector<int> got;
-    const char *q = line + want.size();
-    while (*q && *q != '\n') {
-      char *end = nullptr;
-      const long v = strtol(q, &end, 10);
-      if (end == q) break;
-      const int main_tile = (int)(v & 15), tail = (int)((v >> 4) & 15);
-      if (v < 0 || v >= 0x200 || main_tile >= tsm::kNumTiles || tail >= tsm::kNumTiles) { got.clear(); break; }
-      got.push_back((int)v);
-      q = (*end == ',') ? end + 1 : end;
-    }
-    if (got.size() == codes->size()) {
-      *codes = got;
-      ok = true;
-    }
-  }
+  while (!ok && fgets(line, sizeof line, f)) ok = parse_tune_line(line, want, tsm::kNumTiles, codes);
   fclose(f);
   return ok;
 }
@@ -407,14 +303,12 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     }
     tiles = &it->second;
   }
-  // A tile code is `main + 16 * tail`: tail == 0 -> one launch with tile `main`; otherwise the first rows
-  // go to `main` tiles (a whole number of full-occupancy rounds) and the rest to `tail` tiles on stream2.
-  // Every output element accumulates its K in the same order whatever the tiling, so codes are bit-neutral.
-  // Bit 8 of a code = split-K form of a segmented layer: one workgroup per (tile, K segment) writes raw segment
-  // sums, splitk_reduce adds them in segment order and applies bias / ReLU: bit-identical to the unsplit launch.
+  // A tile code is a ConvTile, plus 0x100 for the split-K form of a segmented layer: one workgroup per (tile, K
+  // segment) writes raw segment sums, splitk_reduce adds them in segment order and applies bias / ReLU --
+  // bit-identical to the unsplit launch.  Every output element accumulates its K in the same order whatever the
+  // tiling, so codes are bit-neutral.
   auto launch_code = [&](tsm::ConvParams p, int ks, int code) -> hipError_t {
-    const int main_tile = code & 15, tail_tile = (code >> 4) & 15;
-    p.tile = main_tile;
+    p.tile = code & 15;
     // A cached code may come from a smaller batch of the same bucket: the scratch-size condition is re-checked on
     // EVERY launch (falling back to the whole-K form, which gives the same bits).
     if ((code & 0x100) && p.kseg_len > 0 &&
@@ -427,32 +321,20 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
         st = tsm::launch_splitk_reduce(e->d_partial, tsm::conv_num_segments(p), p.M, p.Cout, p.bias, nullptr, y, p.relu, s);
       return st;
     }
-    if (tail_tile == 0) return tsm::launch_conv(p, ks, s);
-    int bm, bn;
-    tsm::conv_tile_dims(main_tile, &bm, &bn);
-    const int ntn = p.Cout / bn, ntm = (p.M + bm - 1) / bm;
-    const long slots = (long)e->n_cu * (bm == 64 ? 5 : 2);  // resident workgroups of the coarse kernel
-    const long full = ((long)ntm * ntn / slots) * slots;      // tiles in whole rounds
-    const int mt = (int)(full / ntn);                         // m-tiles fully covered by them
-    if (mt <= 0 || mt >= ntm) return tsm::launch_conv(p, ks, s);
-    hipError_t st = hipEventRecord(e->ev_fork, s);
-    if (st == hipSuccess) st = hipStreamWaitEvent(e->stream2, e->ev_fork, 0);
-    tsm::ConvParams pm = p, pt = p;
-    pm.m_begin = 0; pm.m_end = mt * bm;
-    pt.m_begin = mt * bm; pt.m_end = p.M; pt.tile = tail_tile;
-    if (st == hipSuccess) st = tsm::launch_conv(pm, ks, s);
-    if (st == hipSuccess) st = tsm::launch_conv(pt, ks, e->stream2);
-    if (st == hipSuccess) st = hipEventRecord(e->ev_join, e->stream2);
-    if (st == hipSuccess) st = hipStreamWaitEvent(s, e->ev_join, 0);
-    return st;
+    return tsm::launch_conv(p, ks, s);
+  };
+  // A code read from TSM_TUNE_CACHE (or forced through the environment) is only trusted after it has been checked
+  // against THIS layer: anything else falls back to the heuristic shape, so a stale, foreign or hand-edited cache
+  // line can only cost speed.
+  auto code_ok = [&](const tsm::ConvParams &p, int code) {
+    return code > 0 && (code & ~0x10F) == 0 && tsm::conv_tile_valid(p, code & 15);
   };
   auto conv = [&](int idx, tsm::ConvParams p, int ks, bool is3x3) -> int {
     if (!tuning) {
       int code = tiles ? (*tiles)[idx] : 0;
-      const char *force_code = getenv("TSM_CONV_CODE");  // tuning hook: force one tile code everywhere
-      if (force_code && tsm::conv_tile_valid(p, atoi(force_code) & 15)) {
-        code = atoi(force_code);   // (launch_code ignores the split bit where it does not apply)
-      }
+      if (e->force_tile) code = e->force_tile;
+      if (e->force_code >= 0) code = e->force_code;   // (launch_code ignores the split bit where it does not apply)
+      if (!code_ok(p, code)) code = 0;
       TSM_LAUNCH_K(e, s, is3x3, launch_code(p, ks, code));
       return TSM_OK;
     }
@@ -472,9 +354,6 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       for (int t = 1; t < tsm::kNumTiles; ++t)
         if (tsm::conv_tile_valid(p, t)) cands.push_back(t);
     }
-    // The coarse + tail code (64x64 rounds, 32x32 single-wave tiles for the leftover rows on stream2) is NOT
-    // a candidate: measured slower than plain 64x64 on every layer at batch 32 (layer4 conv2 522 vs 489 us),
-    // see DESIGN.md; TSM_CONV_CODE=67 still forces it for experiments.
     for (int t : cands) {
       float ms[3];
       for (int rep = 0; rep < 3; ++rep) {
@@ -644,6 +523,8 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (const char *fd = getenv("TSM_FUSE_DOWNSAMPLE")) e->fuse_down = atoi(fd) != 0;
   if (const char *sd = getenv("TSM_STEM_DIRECT")) e->stem_direct = atoi(sd) != 0;
   if (const char *sp = getenv("TSM_STEM_POOL")) e->stem_pool = atoi(sp) != 0;
+  if (const char *ft = getenv("TSM_CONV_TILE")) e->force_tile = tsm::conv_tile_from_name(ft);
+  if (const char *fc = getenv("TSM_CONV_CODE")) e->force_code = atoi(fc);
   if (const char *tc = getenv("TSM_TUNE_CACHE")) {
     hipDeviceProp_t prop;
     e->tune_path = tc;
@@ -656,9 +537,6 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   build_topology(e);
   st = hipSetDevice(cfg->device_id);
   if (st == hipSuccess) st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-  if (st == hipSuccess) st = hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking);
-  if (st == hipSuccess) st = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
-  if (st == hipSuccess) st = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
   if (st == hipSuccess) st = hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device_id);
   if (st == hipSuccess) st = hipEventCreate(&e->ev0);
   if (st == hipSuccess) st = hipEventCreate(&e->ev1);
@@ -680,9 +558,6 @@ void tsm_destroy(tsm_engine *e) {
     for (hipEvent_t ev : v)
       if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
-  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-  if (e->stream2) (void)hipStreamDestroy(e->stream2);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -1048,7 +923,10 @@ int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const fl
   }
   tsm::ConvParams p = make_params(c, xin, rin, yout, n, hi, wi, relu != 0, shift_segments,
                                   fold_div > 0 ? fold_div : 1, prec);
+  // (a test / debug entry point that packs weights and allocates on every call: its tuning hooks are read per call)
   const char *sd_env = getenv("TSM_STEM_DIRECT");
+  const int forced = tsm::conv_tile_from_name(getenv("TSM_CONV_TILE"));
+  if (forced && tsm::conv_tile_valid(p, forced)) p.tile = forced;
   hipError_t st;
   if (stem && x3 && cout == 64 && !(sd_env && atoi(sd_env) == 0))
     st = tsm::launch_stem_direct(xin, c.d_w, c.d_b, yout, n, hi, wi, c.kp, relu != 0, prec, s);

@@ -30,9 +30,6 @@ struct ConvParams {
   const float *x2;
   int C2, Hi2, Wi2, stride2;
   int K1;    // channels of the first source (its K extent); Kp = K1 + C2
-  // Row range of this launch, [m_begin, m_end) of the M output pixels (m_end <= 0: all of them).  Lets a
-  // layer be covered by two launches with different tile shapes (coarse tiles + fine tiles for the tail).
-  int m_begin, m_end;
   // Segmented K accumulation (fp32, 64x64 / 32x32 tiles): kseg_len > 0 sums K in consecutive segments of kseg_len
   // K-steps, each from a zero accumulator, and adds the segment sums in order:  out = ((0 + s0) + s1) + ...
   // This fixes the summation order independently of how the work is launched, so the SAME layer can run as one
@@ -51,6 +48,8 @@ enum ConvTile {
   kNumTiles = 6
 };
 void conv_tile_dims(int tile, int *bm, int *bn);
+// "128x128" | "128x64" | "64x64" | "32x32" | "128x128w8" -> ConvTile (kTileAuto for anything else).
+int conv_tile_from_name(const char *name);
 // Is `tile` usable for this problem (Cout divisibility)?
 bool conv_tile_valid(const ConvParams &p, int tile);
 

@@ -6,8 +6,7 @@
 //                    layout (128x128 on 4 or 8 waves, 128x64, 64x64, 32x32 on one wave), KS, SHIFT (fused
 //                    temporal shift), RES (residual prefetched under the K loop), PREC (exact-fp32 MFMA /
 //                    split-bf16 x3 / bf16), DUAL (second A source concatenated along K = conv3 + downsample in
-//                    one GEMM), RKT (fp32 64x64 pipeline: 2 LDS buffers / register-resident K-step / LDS-DMA),
-//                    SEG (fp32 long-K layers: K summed in fixed segments, which makes whole-K and split-K
+//                    one GEMM), SEG (fp32 long-K layers: K summed in fixed segments, which makes whole-K and split-K
 //                    launches of a layer bit-identical; splitk_reduce adds the segment sums in order).
 //                    Every variant accumulates each output in the same k order: results are bit-identical
 //                    across tile shapes, pipelines and launch forms of one precision.
@@ -94,11 +93,10 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 //                32-byte group [hi x8 | lo x8] (same 4 bytes per element, same byte offsets as fp32, so the
 //                loader is shared).  a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_bf16 with fp32
 //                accumulation: relative error ~2^-17 per product, three MFMAs at 16x the fp32-MFMA rate.
-template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false, int RKT = 1,
-          bool SEG = false>
+template <int BM, int BN, int WGM, int WGN, int KS, bool SHIFT, bool RES, int PREC, bool DUAL = false, bool SEG = false>
 // (second launch-bounds argument = minimum waves per SIMD: the SEG 64x64 kernel needs 16 registers more than the
 // plain one and would drop from 5 to 4 workgroups per CU; asking for 5 costs 1-2 spills outside the K loop)
-__global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) ? 5 : 1) conv_igemm(const ConvParams p) {
+__global__ void __launch_bounds__(64 * WGM * WGN, (SEG && BM == 64) ? 5 : 1) conv_igemm(const ConvParams p) {
   static_assert(!SEG || (PREC == kPrecF32 && !RES && WGM * WGN <= 4 && BM == BN && BM <= 64),
                 "segmented K accumulation: fp32, 64x64 / 32x32 tiles, no residual (ConvParams::kseg_len)");
   static_assert(WGM * WGN == 4 || WGM * WGN == 1 || WGM * WGN == 8,
@@ -114,21 +112,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int APASS = BM / LRP, BPASS = BN / LRP;
-  // RK ("register-resident K-step", fp32 64x64 tiles): ONE LDS buffer; after the barrier that makes a
+  // RK ("register-resident K-step", fp32 64x64 / 32x32 tiles): ONE LDS buffer; after the barrier that makes a
   // tile visible every wave pulls all four k-groups of fragments into registers, a second barrier frees the
   // buffer, and the 16 MFMAs of the step then run from registers while the next tile is written into LDS.
   // Half the LDS per workgroup -> more workgroups per CU, and no LDS wait inside the MFMA sequence.
-  constexpr bool RK = RKT != 0 && PREC == kPrecF32 && ((BM == 64 && BN == 64) || (BM == 32 && BN == 32));
-  // RKT == 2: the single buffer is filled by LDS-DMA (buffer_load ... lds): no staging registers, no
-  // ds_write.  The DMA image is lane-linear (1 KiB per wave-instruction = 8 rows x 128 B), so rows are
-  // NOT padded; bank conflicts are removed by an XOR swizzle of the 16-byte chunk index with
-  // f(row) = (row >> 1) & 7, applied on the per-lane SOURCE offset and on the fragment reads.
-  constexpr bool DMA = RK && RKT == 2 && NT == 256;
-  constexpr int LDR = DMA ? 32 : kLds;  // LDS row stride in floats
+  constexpr bool RK = PREC == kPrecF32 && ((BM == 64 && BN == 64) || (BM == 32 && BN == 32));
   constexpr int NBUF = RK ? 1 : 2;
   constexpr int CLD = BN + 4;  // epilogue staging row stride (floats)
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
-  constexpr int SMEM_FLOATS = NBUF * (BM + BN) * LDR > BM * CLD ? NBUF * (BM + BN) * LDR : BM * CLD;
+  constexpr int SMEM_FLOATS = NBUF * (BM + BN) * kLds > BM * CLD ? NBUF * (BM + BN) * kLds : BM * CLD;
 
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
 
@@ -149,7 +141,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
     tile -= seg * (p.ntm * p.ntn);
   }
   const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
-  const int m0 = p.m_begin + tm * BM, n0 = tn * BN;   // m_begin: this launch covers rows [m_begin, m_end)
+  const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- descriptors, rebased to this workgroup's first input frame / first weight row ------------
   const int HoWo = p.Ho * p.Wo;
@@ -176,9 +168,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
       (int)(a2_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : a2_bytes), 0x00020000);
 
   // ---- per-thread loader state: 8 threads per 32-float row, 32 rows per pass -------------------
-  // DMA: this lane fills LDS slot (row, tid & 7), which holds global chunk (tid & 7) ^ f(row)
   const int lrow = tid >> 3;
-  const int chunk = DMA ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);
+  const int chunk = tid & 7;
   const int frame_bytes = (int)(frame_elems * EB);
   unsigned a_off[APASS];                       // byte offset of (row, tap 0, this thread's chunk)
   unsigned a_offp[SHIFT ? APASS : 1], a_offm[SHIFT ? APASS : 1];
@@ -188,7 +179,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
 #pragma unroll
   for (int pp = 0; pp < APASS; ++pp) {
     const int m = m0 + lrow + LRP * pp;
-    const bool ok = m < p.m_end;
+    const bool ok = m < p.M;
     const int mm = ok ? m : m0;
     const int n = mm / HoWo;
     const int rem = mm - n * HoWo;
@@ -314,48 +305,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
       *reinterpret_cast<f32x4 *>(As + (lrow + LRP * item) * kLds + chunk * 4) = ra[item];
     else
       *reinterpret_cast<f32x4 *>(As + BM * kLds + (lrow + LRP * (item - APASS)) * kLds + chunk * 4) = rb[item - APASS];
-  };
-
-  // LDS-DMA item: the same offsets as gload_item, but the 16 bytes of every lane land directly in LDS
-  // (wave-uniform base + lane * 16); out-of-range lanes are written as zeros by the hardware.
-  auto dma_item = [&](const KStep &k, int kt, int item) {
-    unsigned voff, soff = 0;
-    __amdgpu_buffer_rsrc_t rs = rsrcA;
-    int row0;
-    if (item < APASS) {
-      const int pp = item;
-      row0 = 32 * pp;
-      if (KS == 1) {
-        unsigned off = a_off[pp];
-        if (SHIFT) off = (a_offp[pp] & k.mp) | (a_offm[pp] & k.mm) | (a_off[pp] & k.m0);
-        if (DUAL) {
-          const bool second = kt >= nk1;
-          rs = second ? rsrcA2 : rsrcA;
-          voff = (second ? a_off2[pp] : off) | k.dead;
-          soff = second ? k.kbytes - (unsigned)nk1 * 128u : k.kbytes;
-        } else {
-          voff = off | k.dead;
-          soff = k.kbytes;
-        }
-      } else if (KS == 3) {
-        voff = (((a_mask[pp] >> k.tap) & 1u) ? a_off[pp] + (unsigned)k.tap_off : kInvalid) | k.dead;
-      } else {
-        const int tap = kt * 8 + chunk;
-        const int ky = tap / 7, kx = tap - ky * 7;
-        const int iy = a_iy[pp] + ky, ix = a_ix[pp] + kx;
-        const bool ok = tap < 49 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-        voff = (ok ? a_off[pp] + (unsigned)((iy * p.Wi + ix) * 16) : kInvalid) | k.dead;
-      }
-    } else {
-      const int pp = item - APASS;
-      row0 = BM + 32 * pp;
-      rs = rsrcB;
-      voff = b_off[pp] | k.dead;
-      soff = k.kbytes;
-    }
-    float *dst = smem + (row0 + 8 * wave) * LDR;  // wave-uniform: this wave's 8 rows of the pass
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)dst, 16, (int)voff,
-                                             (int)soff, 0, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -490,7 +439,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
   f32x4 rres[(RES && !X3 && !BF) ? EPASS : 1];
   u32x4 rres_h[(RES && (X3 || BF)) ? EPASS : 1], rres_l[(RES && X3) ? EPASS : 1];
   if (RES && (X3 || BF)) {
-    const size_t r_bytes = ((size_t)p.m_end - m0) * p.Cout * EB;
+    const size_t r_bytes = ((size_t)p.M - m0) * p.Cout * EB;
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.res) + (size_t)m0 * p.Cout * EB), 0,
         (int)(r_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : r_bytes), 0x00020000);
@@ -502,7 +451,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
     }
   }
   if (RES && !X3 && !BF) {
-    const size_t r_bytes = ((size_t)p.m_end - m0) * p.Cout * 4;
+    const size_t r_bytes = ((size_t)p.M - m0) * p.Cout * 4;
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.res + (size_t)m0 * p.Cout), 0,
         (int)(r_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : r_bytes), 0x00020000);
@@ -556,11 +505,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
   // out of the inner loop on purpose: inside it the compiler if-converts the flush and drains the MFMA chain on
   // every K-step).  Without SEG there is a single pass over [kt0, nk).
   const int seg_len = (SEG && p.kseg_len > 0) ? p.kseg_len : 0x3fffffff;
-  if constexpr (DMA) {
-    const KStep k0 = kstep(kt0, nk);
-#pragma unroll
-    for (int it = 0; it < NITEMS; ++it) dma_item(k0, kt0, it);
-  } else {
+  {
     const KStep k0 = kstep(kt0, nk);
 #pragma unroll
     for (int it = 0; it < NITEMS; ++it) gload_item(k0, kt0, it);
@@ -570,7 +515,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
 #pragma unroll
     for (int it = 0; it < NITEMS; ++it) gload_item(k1, kt0 + 1, it);
   }
-  __syncthreads();  // (waits for outstanding LDS-DMA too: it is a pending LDS write on the VM counter)
+  __syncthreads();
   if constexpr (BF) {
     // plain bf16: four k16-groups of TM*TN MFMAs per K-step.  Groups 0-1 carry the ds_writes of tile kt+1
     // and the buffer loads of tile kt+2; groups 2-3 run after the barrier and cover the next fragments.
@@ -596,40 +541,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
       __builtin_amdgcn_sched_barrier(0);
       frag_load_bf(cur ^ 1, 1);
       __builtin_amdgcn_sched_barrier(0);
-    }
-  } else if constexpr (DMA) {
-    f32x4 ra_[4], rb_[4];  // all four k-groups of this wave's A / B fragments (TM = TN = 1)
-    const int fsw = (l31 >> 1) & 7;  // f(row) of this lane's fragment row (tile offsets are multiples of 32)
-    for (int kt = kt0; kt < nk;) {
-    const int kend = (SEG && kt + seg_len < nk) ? kt + seg_len : nk;
-    for (; kt < kend; ++kt) {
-      const KStep k1 = kstep(kt + 1, nk);
-      {
-        const float *As = smem + (wm * WTM + l31) * LDR;
-        const float *Bs = smem + (BM + wn * WTN + l31) * LDR;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int slot = ((kk * 2 + half) ^ fsw) * 4;
-          ra_[kk] = *reinterpret_cast<const f32x4 *>(As + slot);
-          rb_[kk] = *reinterpret_cast<const f32x4 *>(Bs + slot);
-        }
-      }
-      __syncthreads();  // every wave holds its fragments: the buffer may be overwritten
-      int cnt = 0;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_[kk][s4], rb_[kk][s4], acc[0][0], 0, 0, 0);
-          ++cnt;
-          if (cnt <= NITEMS) {  // one DMA item behind each of the first MFMAs: tile kt+1 streams in under the rest
-            dma_item(k1, kt + 1, cnt - 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      __syncthreads();  // vmcnt(0) + barrier: tile kt+1 is complete in LDS
-    }
-    seg_flush();
     }
   } else if constexpr (RK) {
     f32x4 ra_[4], rb_[4];  // all four k-groups of this wave's A / B fragments (TM = TN = 1)
@@ -743,7 +654,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && RKT == 1 && BM == 64) 
   // Stores go through a descriptor that ends at row M: rows past the end are dropped by the range
   // check, which keeps the epilogue branch-free (no per-pass wait on earlier stores).
   const bool partial = SEG && p.ksplit;  // raw segment sums to y = partial[seg][M][Cout]: no bias, no ReLU
-  const size_t y_bytes = ((size_t)p.m_end - m0) * p.Cout * EB;
+  const size_t y_bytes = ((size_t)p.M - m0) * p.Cout * EB;
   const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char *>(p.y) + ((size_t)(partial ? seg : 0) * p.M + m0) * p.Cout * EB, 0,
       (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
@@ -826,24 +737,17 @@ static hipError_t launch_conv_seg(ConvParams p, hipStream_t s) {
   if constexpr (!((BM == 64 && BN == 64) || (BM == 32 && BN == 32))) {
     return hipErrorInvalidValue;
   } else {
-    p.ntm = (p.m_end - p.m_begin + BM - 1) / BM;
+    p.ntm = (p.M + BM - 1) / BM;
     p.ntn = p.Cout / BN;
     const dim3 grid((unsigned)(p.ntm * p.ntn * (p.ksplit ? conv_num_segments(p) : 1)));
     const dim3 block(64 * WGM * WGN);
-    const char *rk_env = getenv("TSM_CONV_RK");
-    const int rk = rk_env ? atoi(rk_env) : 1;
     if constexpr (KS == 1 && !SHIFT) {
       if (p.x2) {
-        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecF32, true, 1, true>), grid, block, 0, s, p);
+        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecF32, true, true>), grid, block, 0, s, p);
         return hipGetLastError();
       }
     }
-    if (rk == 0)
-      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, false, kPrecF32, false, 0, true>), grid, block, 0, s, p);
-    else if (rk == 2)
-      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, false, kPrecF32, false, 2, true>), grid, block, 0, s, p);
-    else
-      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, false, kPrecF32, false, 1, true>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, false, kPrecF32, false, true>), grid, block, 0, s, p);
     return hipGetLastError();
   }
 }
@@ -854,7 +758,7 @@ static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
     if constexpr (!RES && KS != 7) return launch_conv_seg<BM, BN, WGM, WGN, KS, SHIFT>(p, s);
     else return hipErrorInvalidValue;
   }
-  p.ntm = (p.m_end - p.m_begin + BM - 1) / BM;
+  p.ntm = (p.M + BM - 1) / BM;
   p.ntn = p.Cout / BN;
   const dim3 grid((unsigned)(p.ntm * p.ntn));
   if constexpr (KS == 1 && !SHIFT && !RES) {
@@ -872,19 +776,8 @@ static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
     hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16x3>), grid, dim3(64 * WGM * WGN), 0, s, p);
   else if (p.prec == kPrecBf16)
     hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16>), grid, dim3(64 * WGM * WGN), 0, s, p);
-  else {
-    // fp32 64x64 pipeline variant: 0 = two LDS buffers, 1 = register-resident K-step (default), 2 = the same
-    // fed by LDS-DMA.  All three accumulate in the same order (bit-identical results); measured within
-    // 1.5 % of each other, 1 marginally ahead.  Read per launch so tests can switch it.
-    const char *rk_env = getenv("TSM_CONV_RK");
-    const int rk = rk_env ? atoi(rk_env) : 1;
-    if (BM == 64 && BN == 64 && rk == 0)
-      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32, false, 0>), grid, dim3(64 * WGM * WGN), 0, s, p);
-    else if (BM == 64 && BN == 64 && rk == 2)
-      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32, false, 2>), grid, dim3(64 * WGM * WGN), 0, s, p);
-    else
-      hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32>), grid, dim3(64 * WGM * WGN), 0, s, p);
-  }
+  else
+    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32>), grid, dim3(64 * WGM * WGN), 0, s, p);
   return hipGetLastError();
 }
 
@@ -898,18 +791,17 @@ void conv_tile_shape(const ConvParams &p, int *bm, int *bn) {
     BM = 64;
     BN = 64;
   }
-  // Tuning hook (tools/ sweeps only): TSM_CONV_TILE=128x64 | 64x64 | 128x128 forces a shape.
-  const char *force = getenv("TSM_CONV_TILE");  // read per launch so tests can switch it
-  if (force) {
-    int fm = 0, fn = 0;
-    if (sscanf(force, "%dx%d", &fm, &fn) == 2 && p.Cout % fn == 0 &&
-        ((fm == 128 && (fn == 128 || fn == 64)) || (fm == 64 && fn == 64) || (fm == 32 && fn == 32 && p.prec == kPrecF32))) {
-      BM = fm;
-      BN = fn;
-    }
-  }
   *bm = BM;
   *bn = BN;
+}
+
+int conv_tile_from_name(const char *name) {
+  if (!name) return kTileAuto;
+  static const struct { const char *n; int t; } names[] = {{"128x128", kTile128x128}, {"128x64", kTile128x64},
+      {"64x64", kTile64x64}, {"32x32", kTile32x32}, {"128x128w8", kTile128x128w8}};
+  for (const auto &e : names)
+    if (strcmp(name, e.n) == 0) return e.t;
+  return kTileAuto;
 }
 
 bool conv_tile_valid(const ConvParams &p, int tile) {
@@ -933,10 +825,6 @@ static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
   ConvParams p = p_in;
   int bm, bn;
   conv_tile_shape(p, &bm, &bn);
-  if (p.tile == kTileAuto) {  // tuning hook: TSM_CONV_TILE=128x128w8 forces the 8-wave form where it is valid
-    const char *force = getenv("TSM_CONV_TILE");
-    if (force && strcmp(force, "128x128w8") == 0 && conv_tile_valid(p, kTile128x128w8)) p.tile = kTile128x128w8;
-  }
   if (p.tile != kTileAuto) {
     if (!conv_tile_valid(p, p.tile)) return hipErrorInvalidValue;
     conv_tile_dims(p.tile, &bm, &bn);
@@ -958,11 +846,6 @@ static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
 
 hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
   ConvParams p = p_in;
-  if (p.m_end <= 0) {  // whole problem
-    p.m_begin = 0;
-    p.m_end = p.M;
-  }
-  if (p.m_begin < 0 || p.m_begin >= p.m_end || p.m_end > p.M || p.m_begin % 32 != 0) return hipErrorInvalidValue;
   const int kc = p.prec == kPrecBf16 ? 64 : kBK;  // channels per K-step
   if (p.Cout % 64 != 0 || p.Kp % kc != 0 || p.M <= 0) return hipErrorInvalidValue;
   if ((1 << p.logC4) * 4 != p.C) return hipErrorInvalidValue;
@@ -972,7 +855,7 @@ hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
     return hipErrorInvalidValue;
   if (p.prec != kPrecF32 && p.prec != kPrecBf16x3 && p.prec != kPrecBf16) return hipErrorInvalidValue;
   if (p.kseg_len < 0 || (p.kseg_len > 0 && (p.prec != kPrecF32 || p.res || ks == 7))) return hipErrorInvalidValue;
-  if (p.ksplit && (p.kseg_len <= 0 || p.m_begin != 0 || p.m_end != p.M)) return hipErrorInvalidValue;
+  if (p.ksplit && p.kseg_len <= 0) return hipErrorInvalidValue;
   if (p.prec != kPrecF32 && p.T > 0 && p.fold % 8 != 0) return hipErrorInvalidValue;
   // stem: 4 channels per pixel (3 + a zero); the bf16 formats read pixel pairs, which needs stride 2 / pad 3
   if (ks == 7 && (p.C != 4 || (p.prec != kPrecF32 && (p.stride != 2 || p.pad != 3)))) return hipErrorInvalidValue;

@@ -17,10 +17,33 @@ import torch
 import torch.distributed as dist
 
 
+_force_collective = False
+
+
 def world_info() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def set_force_collective(on: bool) -> None:
+    """With a process group of ONE rank the exchange step is the identity and is normally skipped.  ``True`` runs the
+    collectives anyway (pad -> all-gather -> trim on the group's backend): this is how a single-GPU box exercises the
+    real ``nccl`` (= RCCL) branch -- device-tensor all-gathers, ``device_id=`` initialisation -- before a multi-GPU
+    node does (tests/test_rccl_gpu.py, ``bench.py`` under TSM_BENCH_FORCE_COLLECTIVE=1)."""
+    global _force_collective
+    _force_collective = bool(on)
+
+
+def collective_enabled() -> bool:
+    """True when the data-path collectives must run: more than one rank, or forced on an initialised group."""
+    rank, world = world_info()
+    return world > 1 or (_force_collective and dist.is_available() and dist.is_initialized())
+
+
+def on_rccl() -> bool:
+    """The process group moves CUDA tensors (backend ``nccl`` = RCCL over xGMI on ROCm)."""
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl'
 
 
 def per_rank(n_items: int, world: int) -> int:
@@ -37,7 +60,7 @@ def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
 def all_gather_logits(local: torch.Tensor, group=None) -> torch.Tensor:
     """[per, C] on every rank (same ``per`` everywhere) -> [W*per, C] in rank order, on every rank."""
     rank, world = world_info()
-    if world == 1:
+    if not collective_enabled():
         return local
     local = local.contiguous()
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -50,7 +73,7 @@ def gather_clip_logits(local: torch.Tensor, n_total: int, group=None) -> torch.T
     ``per_rank`` rows, possibly none).  Pads to ``per_rank`` rows, all-gathers once, trims to
     ``n_total`` rows in global clip order."""
     rank, world = world_info()
-    if world == 1:
+    if not collective_enabled():
         return local[:n_total]
     per = per_rank(n_total, world)
     lo, hi = shard_range(n_total, world, rank)

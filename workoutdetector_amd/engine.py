@@ -227,11 +227,9 @@ class TsmEngine:
 
     @classmethod
     def tile_name(cls, code: int) -> str:
-        """``main + 16 * tail + 256 * split``: e.g. '64x64+32x32' = coarse 64x64 tiles for the rows that fill whole
-        rounds of the chip, single-wave 32x32 tiles (second stream) for the remaining rows; '64x64/splitK' = one
-        workgroup per (tile, K segment) + ordered reduction (segmented fp32 layers at small batch)."""
-        main, tail, split = code & 15, (code >> 4) & 15, code >> 8
-        return cls.TILE_NAMES[main] + ('+' + cls.TILE_NAMES[tail] if tail else '') + ('/splitK' if split else '')
+        """``tile + 256 * split``: '64x64/splitK' = one workgroup per (tile, K segment), combined in segment order
+        (segmented fp32 layers at small batch)."""
+        return cls.TILE_NAMES[code & 15] + ('/splitK' if code >> 8 else '')
 
     def conv_tiles(self, n_clips: int) -> Dict[str, str]:
         """Tile shape the autotuner chose per conv launch for an ``n_clips`` forward."""

@@ -1,8 +1,8 @@
 """Evaluate score files: scores -> states -> counts -> MAE / OBO.
 
 Counterpart of workoutdetector/utils/eval.py: ``main`` :117-180 (softmax option, arg-max,
-``score >= 0.5`` else -1, ``pred_to_count(step=8)``, ``obo_mae``), ``obo_mae`` :11-24 and the
-per-action summary of ``analyze_count`` :58-114.
+``score >= 0.5`` else -1, ``pred_to_count(step=8)``, ``obo_mae``), ``obo_mae`` :11-24 and
+``analyze_count(csv, out_csv)`` :58-114 (same signature, CSV schema and arithmetic).
 """
 from __future__ import annotations
 
@@ -10,6 +10,7 @@ import json
 import os
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import pandas as pd
 
 from .counting import obo_mae, pred_to_count, to_softmax  # noqa: F401  (re-export)
@@ -60,8 +61,46 @@ def main(json_dir: str, anno_path: str, out_csv: Optional[str], softmax: bool = 
     return mae, obo
 
 
-def analyze_count(df: pd.DataFrame) -> pd.DataFrame:
-    """Per (split, action): videos, MAE (un-normalised), OBO (|diff| == 1), mean |diff|/gt."""
+def analyze_count(csv: str, out_csv: Optional[str]) -> None:
+    """Per-(split, action) summary of an evaluation CSV: drop-in for utils/eval.py:58-114.
+
+    ``csv`` is what ``main`` writes (columns ``,name,gt_count,pred_count,gt_rep,pred_rep,split,action``); the
+    result has columns ``,action,split,mae,obo_acc,total,avg_count`` -- one row per (split, action) in order of first
+    appearance, splits outermost, then one ``action == 'all'`` row per split -- and goes to ``out_csv`` (if given)
+    and to stdout, like the reference.  Reference arithmetic kept as is: ``obo_acc`` is the COUNT of videos with
+    ``|pred - gt| == 1`` (``obo_mae(ratio=False)``), not a fraction; the per-split MAE re-accumulates
+    ``int(mae * n)`` per action (truncating); a (split, action) pair without videos raises ZeroDivisionError."""
+    df = pd.read_csv(csv, index_col='name')
+    actions, splits = df.action.unique(), df.split.unique()
+    rows = []
+    per_split = {sp: dict(mae=0, obo=0, total=0, avg_count=0.0) for sp in splits}
+    for sp in splits:
+        acc = per_split[sp]
+        for act in actions:
+            sel = df.loc[(df.action == act) & (df.split == sp)]
+            gt, pred = sel.gt_count.values, sel.pred_count.values
+            mae, obo = obo_mae(pred, gt, ratio=False)
+            rows.append([act, sp, mae, obo, len(sel), np.mean(gt)])
+            acc['mae'] += int(mae * len(sel))
+            acc['obo'] += int(obo)
+            acc['total'] += len(sel)
+            acc['avg_count'] += gt.sum()
+    out = pd.DataFrame(rows, columns=['action', 'split', 'mae', 'obo_acc', 'total', 'avg_count'])
+    for sp in splits:
+        acc = per_split[sp]
+        print(f'{sp}: {acc}')
+        n = acc['total']
+        out = pd.concat([out, pd.DataFrame({'action': 'all', 'split': sp, 'mae': acc['mae'] / n, 'obo_acc': acc['obo'],
+                                            'total': n, 'avg_count': acc['avg_count'] / n}, index=[0])],
+                        ignore_index=True)
+    if out_csv:
+        out.to_csv(out_csv)
+    print(out)
+
+
+def summarize_counts(df: pd.DataFrame) -> pd.DataFrame:
+    """Not in the reference: per (split, action) videos, MAE (un-normalised), OBO as a FRACTION (|diff| == 1) and
+    mean |diff| / gt, from an in-memory frame (the helper this module called ``analyze_count`` before round 2)."""
     out = []
     for (split, action), g in df.groupby(['split', 'action']):
         diff = (g['pred_count'] - g['gt_count']).abs()

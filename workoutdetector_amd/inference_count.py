@@ -269,14 +269,14 @@ def _rank_clip_range(total_frames: int) -> Optional[Tuple[int, int]]:
 def _gather_video_logits(model, local: torch.Tensor, total_frames: int) -> torch.Tensor:
     """All-gather the per-rank blocks of one video's clip logits (no-op in a single process)."""
     rank, world = tdist.world_info()
-    if world == 1:
+    if not tdist.collective_enabled():
         return local
     n = len(clip_starts(total_frames))
     lo, hi = tdist.shard_range(n, world, rank)
     num_class = getattr(model, 'num_class', local.shape[1] if local.numel() else 0)
     local = local.reshape(hi - lo, num_class)
     dev = _engine_device(model)
-    if dev is not None and torch.distributed.get_backend() == 'nccl':
+    if dev is not None and tdist.on_rccl():
         local = local.to(dev)
     return tdist.gather_clip_logits(local, n).cpu()
 
@@ -306,7 +306,7 @@ def _inference_dataset_by_videos(model, items: list, out_dir: str, checkpoint: s
     all-gathers), and rank 0 writes the round's JSON files."""
     rank, world = tdist.world_info()
     dev = _engine_device(model)
-    on_gpu = dev is not None and world > 1 and torch.distributed.get_backend() == 'nccl'
+    on_gpu = dev is not None and tdist.collective_enabled() and tdist.on_rccl()
     num_class = getattr(model, 'num_class', None)
     mine = items[rank::world]
     staged = prefetch_staged(model, ((it, (lambda p=it.video_path: reader(p))) for it in mine))
@@ -321,7 +321,7 @@ def _inference_dataset_by_videos(model, items: list, out_dir: str, checkpoint: s
         else:
             local = torch.empty((0, num_class or 0), dtype=torch.float32)
             meta = torch.zeros(3, dtype=torch.int64)
-        if world == 1:
+        if not tdist.collective_enabled():
             _write_score_json(out_dir, item, checkpoint, local, st.total)
             continue
         metas = tdist.all_gather_logits((meta.to(dev) if on_gpu else meta).reshape(1, 3)).cpu()
@@ -337,16 +337,20 @@ def _inference_dataset_by_videos(model, items: list, out_dir: str, checkpoint: s
 def inference_dataset(model, splits: List[str], out_dir: str, checkpoint: str, person_crop: bool = False,
                       data_root: Optional[str] = None, anno_path: Optional[str] = None,
                       video_reader: Optional[Callable[[str], torch.Tensor]] = None, action: Sequence[str] = ('all',),
-                      batch_clips: int = 32, scale_255: bool = False, shard: str = 'clips') -> None:
+                      batch_clips: int = 32, scale_255: bool = False, shard: Optional[str] = None) -> None:
     """Inference the RepCount dataset; one ``{video_name}.score.json`` per video with the reference's
     schema: video_name, model, input_shape, checkpoint, total_frames, ground_truth, action, scores.
 
     Under ``torch.distributed``: ``shard='clips'`` splits the clips of every video over the ranks (one all-gather per
     video; lowest latency per video, but every rank reads every video), ``shard='videos'`` gives whole videos to ranks
-    round-robin (each video is decoded once; full-size batches; two small all-gathers per W videos)."""
+    round-robin (each video is decoded once; full-size batches; two small all-gathers per W videos).  Default:
+    ``'videos'`` when there is more than one rank (the dataset-throughput form), ``'clips'`` otherwise; ask for
+    ``'clips'`` explicitly for the lowest latency on a single stream."""
+    rank, _world = tdist.world_info()
+    if shard is None:
+        shard = 'videos' if _world > 1 else 'clips'
     if shard not in ('clips', 'videos'):
         raise ValueError("shard must be 'clips' or 'videos'")
-    rank, _world = tdist.world_info()
     if rank == 0 and not os.path.exists(out_dir):
         os.makedirs(out_dir)
     data_root = osp.expanduser(data_root or '~/data/RepCount/')

@@ -66,19 +66,20 @@ def make_state_dict(seed: int = 0, num_class: int = 12) -> 'OrderedDict[str, np.
 
 
 def remap_checkpoint_keys(state_dict: Mapping[str, object], num_class: int) -> 'OrderedDict[str, object]':
-    """Checkpoint ``state_dict`` (``module.``/``model.``-prefixed) -> engine keys."""
-    keys = list(state_dict.keys())
-    fc_w, fc_b = keys[-2], keys[-1]
+    """Checkpoint ``state_dict`` (``module.``/``model.``-prefixed) -> engine keys, exactly as create_model does it
+    (models/tsm.py:451-473; pinned by tests/golden/ref_ckpt_remap.json, produced by executing those statements):
+    the LAST TWO entries are the classifier; they become ``fc.weight`` / ``fc.bias`` iff the weight has ``num_class``
+    rows and are dropped otherwise; every key loses its first dotted component.  Like the reference, a classifier
+    that is already called ``module.fc`` is dropped by the delete that follows the copy -- the reference then keeps
+    its random-init fc (``strict=False``); the engine reports the missing ``fc.weight`` instead of guessing."""
     items = OrderedDict(state_dict)
-    w = items[fc_w]
-    rows = w.shape[0]
-    if rows == num_class:
+    keys = list(items.keys())
+    fc_w, fc_b = keys[-2], keys[-1]
+    if items[fc_w].shape[0] == num_class:
         items['module.fc.weight'] = items[fc_w]
         items['module.fc.bias'] = items[fc_b]
-    if fc_w != 'module.fc.weight':
-        del items[fc_w]
-    if fc_b != 'module.fc.bias':
-        del items[fc_b]
+    del items[fc_w]
+    del items[fc_b]
     return OrderedDict(('.'.join(k.split('.')[1:]), v) for k, v in items.items())
 
 
