@@ -152,9 +152,9 @@ def test_autotuned_tiles_are_bitwise_invariant(hip_lib, sd0, monkeypatch):
 
 def test_create_model_from_checkpoint_and_onnx(hip_lib, sd0, tmp_path):
     """The four weight sources give the same logits: state dict, torch checkpoint with 'module.' keys
-    (create_model's remap, tsm.py:451-473), an mmaction2-style checkpoint and a BN-folded .onnx export."""
-    from tests._onnx_writer import write_model
-    from tests.test_onnx_import import _folded_export
+    (create_model's remap, tsm.py:451-473), an mmaction2-style checkpoint and the reference's deployment artefact: an
+    eval-mode ``torch.onnx.export`` (opset 11, BatchNorm fused) written by torch's exporter (tests/_torch_tsm.py)."""
+    from tests._torch_tsm import LitWrapper, TorchTSM, export_onnx
     from workoutdetector_amd.engine import TsmEngine, create_model
     x = make_input(9, 1, 8, 64, 64)
     ref = TsmEngine(height=64, width=64, max_clips=1, state_dict=sd0)
@@ -172,8 +172,8 @@ def test_create_model_from_checkpoint_and_onnx(hip_lib, sd0, tmp_path):
                      max_clips=1)
     assert np.array_equal(m.run(None, {'input': x})[0], want)
     m.close()
-    nodes, inits = _folded_export({k: v.numpy() for k, v in sd0.items()})
-    write_model(str(tmp_path / 'tsm.onnx'), nodes, inits)
+    export_onnx(LitWrapper(TorchTSM(num_class=12).load_engine_state_dict(sd0)), str(tmp_path / 'tsm.onnx'),
+                sample_shape=(1, 8, 3, 64, 64))
     m = create_model(num_class=12, checkpoint=str(tmp_path / 'tsm.onnx'), device='cuda:0', height=64, width=64, max_clips=1)
     assert_close(m.run(None, {'input': x})[0], want, rtol=1e-5, atol_scale=1e-6, what='onnx-imported weights')
     m.close()

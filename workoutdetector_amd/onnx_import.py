@@ -9,13 +9,16 @@ fields needed) and maps the tensors onto the engine's ``TSM.state_dict()`` keys:
   * initialisers that still carry state-dict names (``...base_model.layer1.0.conv1.net.weight``,
     BatchNormalization inputs ``...bn1.weight/bias/running_mean/running_var``): any prefix in front of
     ``base_model.`` / ``fc.`` / ``new_fc.`` is stripped;
-  * exports where the exporter folded BatchNorm into the convolutions (eval-mode constant folding:
-    anonymous ``onnx::Conv_###`` weight + bias initialisers): the 53 Conv nodes are taken in graph order,
-    which is the module execution order stem, then per Bottleneck conv1, conv2, conv3[, downsample] -- the
-    order of ``weights.conv_specs()`` -- and every conv gets an identity BatchNorm carrying its bias.
+  * exports where the exporter folded BatchNorm into the convolutions (eval-mode Conv+BN fusion: anonymous
+    ``onnx::Conv_###`` weight + bias initialisers): every Conv node is identified by CONNECTIVITY, not by its
+    position in the file -- the number of Conv nodes upstream of it in the dataflow graph fixes its place in the
+    network (conv1 and downsample of a block see the same upstream set, conv2 one more, conv3 two more; the two
+    1x1 convs that share a count always differ in output channels), the weight shape must agree, and anything
+    ambiguous or missing raises -- and every conv gets an identity BatchNorm carrying its bias.
 
-No real export is available offline (weights and .onnx files are git-ignored upstream), so the parser is
-tested against files written by ``tests/_onnx_writer.py`` in both styles.
+Tested on files written by torch's own exporter (``torch.onnx.export(..., opset_version=11)`` of an nn.Module with
+the reference's module tree, both export styles; tests/_torch_tsm.py) and on hand-written files
+(``tests/_onnx_writer.py``) for the malformed cases.
 """
 from __future__ import annotations
 
@@ -140,6 +143,47 @@ def _strip_prefix(name: str) -> str:
     return name
 
 
+def _resolve_convs(path: str, nodes: List[dict], inits: Dict[str, np.ndarray], specs) -> List[dict]:
+    """The Conv node of every entry of ``conv_specs()``, found by dataflow position + weight shape."""
+    convs = [i for i, n in enumerate(nodes) if n['op_type'] == 'Conv']
+    if len(convs) != len(specs):
+        raise ValueError(f'{path}: {len(convs)} Conv nodes, a TSM-ResNet50 has {len(specs)}')
+    bit = {ni: 1 << k for k, ni in enumerate(convs)}
+    upstream: Dict[str, int] = {}          # tensor name -> bitmask of the Conv nodes it depends on
+    depth: Dict[int, int] = {}
+    for ni, n in enumerate(nodes):         # ONNX graphs are topologically sorted
+        m = 0
+        for t in n['input']:
+            m |= upstream.get(t, 0)
+        if ni in bit:
+            depth[ni] = bin(m).count('1')
+            m |= bit[ni]
+        for t in n['output']:
+            upstream[t] = m
+    by_key: Dict[Tuple[int, tuple], List[int]] = {}
+    for ni in convs:
+        w = inits.get(nodes[ni]['input'][1]) if len(nodes[ni]['input']) > 1 else None
+        if w is None:
+            raise ValueError(f'{path}: Conv "{nodes[ni]["name"]}" has no initialiser weight')
+        by_key.setdefault((depth[ni], tuple(w.shape)), []).append(ni)
+    out, before = [], 0                    # `before` = Conv nodes upstream of the current block's input
+    for idx, (wkey, _bnp, cout, cin, k) in enumerate(specs):
+        if idx == 0:
+            want = 0
+        else:
+            role = wkey.rsplit('.', 2)[-2] if '.net.' not in wkey else 'conv1'   # conv2 | conv3 | 0 (downsample) | conv1
+            want = before + {'conv1': 0, '0': 0, 'conv2': 1, 'conv3': 2}[role]
+        cands = by_key.get((want, (cout, cin, k, k)), [])
+        if len(cands) != 1:
+            raise ValueError(f'{path}: {len(cands)} Conv nodes with {want} upstream convs and weight {(cout, cin, k, k)} '
+                             f'for {wkey}; cannot map the graph onto TSM-ResNet50')
+        out.append(nodes[cands[0]])
+        nxt = specs[idx + 1][0] if idx + 1 < len(specs) else ''
+        if idx == 0 or (nxt.endswith('.conv1.net.weight') or nxt == ''):
+            before = idx + 1               # a block is complete: everything so far is upstream of the next one
+    return out
+
+
 def load_onnx_state_dict(path: str, num_class: int) -> 'OrderedDict[str, np.ndarray]':
     """Engine state dict (``TsmEngine.load_state_dict``) from a TSM-R50 ``.onnx`` export."""
     inits, nodes = parse_onnx(path)
@@ -149,15 +193,9 @@ def load_onnx_state_dict(path: str, num_class: int) -> 'OrderedDict[str, np.ndar
         sd = OrderedDict((k, v) for k, v in named.items()
                          if (k.startswith('base_model.') or k.startswith('fc.')) and v.dtype == np.float32)
     else:
-        convs = [n for n in nodes if n['op_type'] == 'Conv']
-        if len(convs) != len(specs):
-            raise ValueError(f'{path}: {len(convs)} Conv nodes, a TSM-ResNet50 has {len(specs)}')
         sd = OrderedDict()
-        for (wkey, bnp, cout, cin, k), node in zip(specs, convs):
-            w = inits.get(node['input'][1])
-            if w is None or tuple(w.shape) != (cout, cin, k, k):
-                raise ValueError(f'{path}: Conv "{node["name"]}" weight {None if w is None else w.shape} does not '
-                                 f'match {wkey} {(cout, cin, k, k)}')
+        for (wkey, bnp, cout, cin, k), node in zip(specs, _resolve_convs(path, nodes, inits, specs)):
+            w = inits[node['input'][1]]
             b = inits[node['input'][2]] if len(node['input']) > 2 else np.zeros(cout, np.float32)
             sd[wkey] = w.astype(np.float32)
             # identity BatchNorm carrying the folded bias: scale = 1/sqrt(var + eps) = 1, bias = beta
