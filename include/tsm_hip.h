@@ -18,6 +18,8 @@
  *                          Bottleneck kept by TSM        workoutdetector/models/tsm.py:250-251,264-281
  *   tsm_maxpool3x3s2       base_model.maxpool
  *   tsm_head               avgpool -> fc -> view(-1,T,cls) -> mean(1)   tsm.py:411-419,165-174
+ *   tsm_scores_to_states   per clip: to_softmax, first arg-max, score >= 0.5 ? class : -1
+ *                          workoutdetector/utils/eval.py:153-164, utils/visualize.py:140-150
  *
  * Conventions
  *   - Plain pointers and sizes only; no torch / HIP types in signatures.  hip streams travel as
@@ -25,7 +27,8 @@
  *     entry points (so work is ordered after whatever produced the buffers there -- torch's default
  *     stream is the null stream), the engine's private stream for TSM_MEM_HOST calls.
  *   - Every function returns 0 on success or a negative tsm_status; the message for the last
- *     failure on an engine is tsm_last_error(engine) (engine == NULL: last create failure).
+ *     failure on an engine is tsm_last_error(engine) (engine == NULL: the calling THREAD's last failure of
+ *     tsm_create or of an engine-less per-op entry point; no process-global state).
  *   - An engine owns its weights and workspace on ONE device; it is NOT re-entrant: one
  *     in-flight call per engine.  Independent engines (other devices / processes) coexist.
  *   - Caller owns all input / output buffers.  With TSM_MEM_HOST the call copies and
@@ -41,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TSM_ABI_VERSION 3 /* 3: TSM_LAYOUT_NTHWC8S / 8B hold one group per pixel pair (was: per pixel) */
+#define TSM_ABI_VERSION 4 /* 4: tsm_scores_to_states; tile codes lost the tail field; TSM_* variables read in tsm_create only */
 
 typedef enum tsm_status {
   TSM_OK = 0,
@@ -188,6 +191,14 @@ int tsm_preprocess(const void *frames, int32_t pixel, int32_t n, int32_t h, int3
 int tsm_head(const float *feat, const float *fc_w, const float *fc_b, float *logits,
              int32_t n_clips, int32_t n_segment, int32_t hw, int32_t c, int32_t num_class,
              void *stream);
+
+/* Scores -> states on the GPU (device pointers), the post-step of the hot path:
+ *   logits [n_clips, num_class] fp32 -> states [n_clips] int32: (softmax != 0: fp32 softmax over the classes,) the FIRST
+ *   maximum, its class id if the score >= threshold, else -1; top_score (nullable) [n_clips] receives that score.
+ * A streaming consumer (count_by_video_model, utils/inference_count.py:285-339) then copies 4-8 bytes per window to
+ * the host instead of the logits and feeds pred_to_count directly. */
+int tsm_scores_to_states(const float *logits, int32_t n_clips, int32_t num_class, int32_t softmax, float threshold,
+                         int32_t *states, float *top_score, void *stream);
 
 #ifdef __cplusplus
 }

@@ -145,3 +145,39 @@ def test_head_reference_consensus_vectors(hip_lib, golden_dir):
         w[torch.arange(c), torch.arange(c)] = 1.0
         got = head_nhwc(feat.cuda(), w.cuda(), torch.zeros(c).cuda(), t).cpu()
         assert_close(got.numpy(), z[f'y{i}'], rtol=1e-6, atol_scale=1e-6, what=f'consensus{i}')
+
+
+def test_scores_to_states_on_gpu_equals_the_host_path(hip_lib, golden_dir):
+    """K9 (tsm_scores_to_states) against counting.scores_to_preds and the reference's executed to_softmax
+    (tests/golden/ref_metrics.json): identical integer states, with and without softmax, at thresholds other than 0.5,
+    ties -> first index, exactly-at-threshold kept (``>=``); probabilities within 2 ulp (expf is the only freedom)."""
+    import json
+
+    from oracle import counting_oracle
+    from workoutdetector_amd.counting import scores_to_preds, softmax_rows
+    from workoutdetector_amd.engine import scores_to_states
+    ref = json.load(open(f'{golden_dir}/ref_metrics.json'))['to_softmax']
+    rows = [[c['scores'][str(j)] for j in range(12)] for c in ref]
+    rng = np.random.default_rng(9)
+    for scale in (0.3, 1.0, 3.0, 10.0):
+        rows += (rng.standard_normal((200, 12)) * scale).astype(np.float32).tolist()
+    rows += [[0.0, 0.0] + [-1000.0] * 10,                      # two-way tie at p = 0.5 exactly: kept, first index
+             [1.0] * 12,                                       # twelve-way tie: class 0, p = 1/12 < 0.5 -> -1
+             [-100.0] * 11 + [5.0], [3.0, 3.0, 2.9] + [0.0] * 9]
+    x = torch.tensor(rows, dtype=torch.float32).cuda()
+    for softmax in (True, False):
+        for thr in (0.5, 0.3, 0.9):
+            st, top = scores_to_states(x, threshold=thr, softmax=softmax, return_top=True)
+            got = st.cpu().tolist()
+            assert got == scores_to_preds(rows, threshold=thr, softmax=softmax), (softmax, thr)
+            assert got == counting_oracle.scores_to_preds(rows, threshold=thr, use_softmax=softmax)
+            p = softmax_rows(np.asarray(rows, np.float32)) if softmax else np.asarray(rows, np.float32)
+            np.testing.assert_allclose(top.cpu().numpy(), p.max(axis=1), rtol=3e-7, atol=0)
+    # the reference's own softmax outputs: the winning probability agrees with the executed to_softmax
+    st, top = scores_to_states(x[:len(ref)], return_top=True)
+    want = np.float32([max(c['softmax'].values()) for c in ref])
+    np.testing.assert_allclose(top.cpu().numpy(), want, rtol=3e-7)
+    # other class counts (numpy's pairwise order only applies from 8 elements on)
+    for c in (2, 5, 8, 17, 130):
+        r = (rng.standard_normal((64, c)) * 2).astype(np.float32)
+        assert scores_to_states(torch.from_numpy(r).cuda()).cpu().tolist() == scores_to_preds(r.tolist())

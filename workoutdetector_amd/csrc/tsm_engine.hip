@@ -993,4 +993,14 @@ int tsm_head(const float *feat, const float *fc_w, const float *fc_b, float *log
   return TSM_OK;
 }
 
+int tsm_scores_to_states(const float *logits, int32_t n_clips, int32_t num_class, int32_t softmax, float threshold,
+                         int32_t *states, float *top_score, void *stream) {
+  if (!logits || !states || n_clips <= 0 || num_class <= 0)
+    return fail(nullptr, TSM_ERR_INVALID_ARG, "scores_to_states: NULL pointer or non-positive size");
+  hipError_t st = tsm::launch_scores_to_states(logits, n_clips, num_class, softmax != 0, threshold, states, top_score,
+                                               static_cast<hipStream_t>(stream));
+  if (st != hipSuccess) return fail(nullptr, TSM_ERR_HIP, std::string("scores_to_states: ") + hipGetErrorString(st));
+  return TSM_OK;
+}
+
 }  // extern "C"

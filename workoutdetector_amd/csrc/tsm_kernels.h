@@ -101,4 +101,8 @@ hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, 
                        float *logits, int n_clips, int n_segment, int hw, int c, int num_class, int prec,
                        hipStream_t s);
 
+// K9: per clip, (softmax,) first arg-max, class id if its score >= threshold else -1; top (nullable) = that score.
+hipError_t launch_scores_to_states(const float *logits, int n, int c, int softmax, float threshold, int *states, float *top,
+                                   hipStream_t s);
+
 }  // namespace tsm

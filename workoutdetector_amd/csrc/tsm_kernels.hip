@@ -1775,4 +1775,64 @@ hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, 
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// K9: logits -> per-clip state on the GPU (utils/eval.py:153-164 + to_softmax, utils/visualize.py:140-150):
+// optional fp32 softmax over the classes, FIRST maximum, class id if its score >= threshold else -1.  One thread per
+// clip (n_clips x num_class is tiny; the point is that a streaming step copies 8 bytes per window to the host instead
+// of the logits, and needs no host-side numpy pass).  The sum runs in numpy's order for rows of 8..128 elements
+// (8 strided partial sums, a fixed tree, then the remainder), so probabilities match the host path up to the 1-ulp
+// freedom of expf itself.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) scores_to_states_kernel(const float *__restrict__ logits, int n, int c, int softmax,
+                                                              float threshold, int *__restrict__ states,
+                                                              float *__restrict__ top) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const float *s = logits + (size_t)i * c;
+  float best = 0.f;
+  int arg = 0;
+  if (softmax) {
+    float mx = s[0];
+    for (int j = 1; j < c; ++j) mx = fmaxf(mx, s[j]);
+    float sum;
+    if (c >= 8 && c <= 128) {
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = expf(s[j] - mx);
+      int j = 8;
+      for (; j + 8 <= c; j += 8)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] += expf(s[j + q] - mx);
+      sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+      for (; j < c; ++j) sum += expf(s[j] - mx);
+    } else {
+      sum = 0.f;
+      for (int j = 0; j < c; ++j) sum += expf(s[j] - mx);
+    }
+    for (int j = 0; j < c; ++j) {
+      const float p = expf(s[j] - mx) / sum;
+      if (j == 0 || p > best) {
+        best = p;
+        arg = j;
+      }
+    }
+  } else {
+    best = s[0];
+    for (int j = 1; j < c; ++j)
+      if (s[j] > best) {
+        best = s[j];
+        arg = j;
+      }
+  }
+  states[i] = best >= threshold ? arg : -1;
+  if (top) top[i] = best;
+}
+
+hipError_t launch_scores_to_states(const float *logits, int n, int c, int softmax, float threshold, int *states, float *top,
+                                   hipStream_t s) {
+  if (!logits || !states || n <= 0 || c <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(scores_to_states_kernel, dim3((n + 63) / 64), dim3(64), 0, s, logits, n, c, softmax, threshold, states, top);
+  return hipGetLastError();
+}
+
 }  // namespace tsm

@@ -402,6 +402,23 @@ def preprocess_frames(frames, resize: int = 256, crop: int = 224, scale_255: boo
     return out
 
 
+def scores_to_states(logits, threshold: float = 0.5, softmax: bool = True, return_top: bool = False):
+    """K9 on the GPU: CUDA float32 logits [n, num_class] -> int32 states [n] (utils/eval.py:153-164: softmax, first
+    arg-max, class id if its score >= threshold else -1) and optionally the winning score.  Enqueues on torch's
+    current stream; no host sync."""
+    import torch
+    _need_cuda_f32(logits=logits)
+    if logits.dim() != 2 or logits.shape[0] == 0:
+        raise ValueError(f'logits must be [n >= 1, num_class], got {tuple(logits.shape)}')
+    logits = logits.contiguous()
+    n, c = logits.shape
+    states = torch.empty(n, dtype=torch.int32, device=logits.device)
+    top = torch.empty(n, dtype=torch.float32, device=logits.device) if return_top else None
+    _lib.check(_lib.load().tsm_scores_to_states(logits.data_ptr(), n, c, int(softmax), float(threshold),
+                                                states.data_ptr(), _ptr(top), _stream(logits)))
+    return (states, top) if return_top else states
+
+
 def maxpool3x3s2_nhwc(x):
     import torch
     _need_cuda_f32(x=x)

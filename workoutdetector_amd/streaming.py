@@ -139,10 +139,12 @@ class StreamBatcher:
             order += [sid for sid, _ in batch]
         if pending:
             if isinstance(pending[0], torch.Tensor):
-                logits = torch.cat(pending).cpu().numpy()           # the step's only host sync
+                # HIP path: softmax / arg-max / threshold on the GPU too (tsm_scores_to_states): one int32 per window
+                # crosses PCIe, in the step's only host sync
+                from .engine import scores_to_states
+                states = scores_to_states(torch.cat(pending), threshold=self.threshold, softmax=self.softmax).cpu().tolist()
             else:
-                logits = np.concatenate(pending)
-            states = scores_to_preds(logits.tolist(), threshold=self.threshold, softmax=self.softmax)
+                states = scores_to_preds(np.concatenate(pending).tolist(), threshold=self.threshold, softmax=self.softmax)
             for sid, state in zip(order, states):
                 st = self.streams[sid]
                 widx = len(st.states)
