@@ -65,7 +65,7 @@ static void fuzz_tune_lines(unsigned seed, int rounds) {
     if (line.size() > 4000) line.resize(4000);
     std::vector<int> codes(5, -7);
     const bool ok = parse_tune_line(line.c_str(), want, kNumTiles, &codes);
-    for (int c : codes) EXPECT(ok ? (c >= 0 && (c & ~0x10F) == 0 && (c & 15) < kNumTiles) : c == -7);
+    for (int c : codes) EXPECT(ok ? (c >= 0 && (c & ~0x50F) == 0 && (c & 15) < kNumTiles) : c == -7);
   }
 }
 

@@ -53,6 +53,10 @@ struct Block {
   float *d_wf = nullptr, *d_bf = nullptr;
   int kpf = 0;
   int ksegf = 0;  // segment length of the fused GEMM
+  // conv2 + conv3 (+ residual) as ONE kernel (tsm::launch_conv23_fused): fp32 blocks without a downsample branch whose
+  // mid tensor has 64 / 128 channels (layer1.1-2, layer2.1-3); d_w3f = conv3's folded weights in fragment order
+  float *d_w3f = nullptr;
+  int cmid = 0;
 };
 
 int ilog2(int v) {
@@ -100,6 +104,8 @@ struct tsm_engine {
   // Tuning hooks, read ONCE in tsm_create (never per launch): TSM_CONV_TILE=<name> forces one tile shape wherever it
   // is valid, TSM_CONV_CODE=<int> one tile code (tile | 0x100 = split-K form); tests and tools/ sweeps only.
   int force_tile = 0, force_code = -1;
+  int fuse23 = -1;   // TSM_FUSE_CONV23: 0 never, 1 wherever a block is eligible, unset: the autotuner times both forms
+  float last_tune_ms = 0.f;   // best time of the layer the tuner measured last (run_forward, tuning pass)
   int n_cu = 256;
   int timing_left = 0;
   bool timing_only3x3 = false;
@@ -327,7 +333,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   // against THIS layer: anything else falls back to the heuristic shape, so a stale, foreign or hand-edited cache
   // line can only cost speed.
   auto code_ok = [&](const tsm::ConvParams &p, int code) {
-    return code > 0 && (code & ~0x10F) == 0 && tsm::conv_tile_valid(p, code & 15);
+    return code > 0 && (code & ~0x50F) == 0 && tsm::conv_tile_valid(p, code & 15);   // (0x400: block runs fused, below)
   };
   auto conv = [&](int idx, tsm::ConvParams p, int ks, bool is3x3) -> int {
     if (!tuning) {
@@ -370,6 +376,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       }
     }
     (*tiles)[idx] = best;
+    e->last_tune_ms = best_ms;
     return TSM_OK;
   };
 
@@ -433,8 +440,29 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     if (rc1) return rc1;
     if (want(name + ".conv1")) return hit(t1, n, h, w, c1.cout);
     tsm::ConvParams p2 = make_params(c2, t1, nullptr, t2, n, h, w, true, 0, 1, prec);
+    // conv2 + conv3 + residual in one kernel where the block is eligible: bit 0x400 of conv2's tile code (set by the
+    // tuning pass when the fused launch beat the two separate ones), or forced / forbidden through TSM_FUSE_CONV23
+    tsm::Fused23Params pf{};
+    const bool can_fuse = blk.d_w3f != nullptr && e->fuse23 != 0 && !want(name + ".conv2");
+    if (can_fuse) {
+      pf.x = t1; pf.w2 = c2.d_w; pf.bias2 = c2.d_b; pf.w3f = blk.d_w3f; pf.bias3 = c3.d_b; pf.res = identity; pf.y = out;
+      pf.N = n; pf.H = h; pf.W = w; pf.M = n * h * w; pf.kseg_len = c2.kseg;
+    }
+    if (can_fuse && !tuning && (e->fuse23 == 1 || (tiles && ((*tiles)[blk.conv2] & 0x400)))) {
+      TSM_LAUNCH_K(e, s, true, tsm::launch_conv23_fused(pf, blk.cmid, s));
+      if (e->cur_timing) {  // keep conv3's launch slot: reported as "not recorded"
+        e->cur_timing->push_back(nullptr);
+        e->cur_timing->push_back(nullptr);
+      }
+      if (want(name)) return hit(out, n, ho, wo, c3.cout);
+      std::swap(cur, out);
+      h = ho; w = wo;
+      if (++bi == kBlocks[li]) { bi = 0; ++li; }
+      continue;
+    }
     int rc2 = conv(blk.conv2, p2, 3, true);
     if (rc2) return rc2;
+    const float ms2 = e->last_tune_ms;
     if (want(name + ".conv2")) return hit(t2, n, ho, wo, c2.cout);
     tsm::ConvParams p3 = make_params(c3, t2, fused ? nullptr : identity, out, n, ho, wo, true, 0, 1, prec);
     if (fused) {
@@ -444,6 +472,17 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     }
     int rc3 = conv(blk.conv3, p3, 1, false);
     if (rc3) return rc3;
+    if (tuning && can_fuse && e->fuse23 < 0) {   // fused form against the two best separate launches (same bits)
+      float ms[3];
+      for (int rep = 0; rep < 3; ++rep) {
+        TSM_HIP(e, hipEventRecord(e->ev0, s));
+        TSM_HIP(e, tsm::launch_conv23_fused(pf, blk.cmid, s));
+        TSM_HIP(e, hipEventRecord(e->ev1, s));
+        TSM_HIP(e, hipEventSynchronize(e->ev1));
+        TSM_HIP(e, hipEventElapsedTime(&ms[rep], e->ev0, e->ev1));
+      }
+      if ((ms[1] < ms[2] ? ms[1] : ms[2]) < ms2 + e->last_tune_ms) (*tiles)[blk.conv2] |= 0x400;
+    }
     if (want(name)) return hit(out, n, ho, wo, c3.cout);
     std::swap(cur, out);
     h = ho; w = wo;
@@ -525,6 +564,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (const char *sp = getenv("TSM_STEM_POOL")) e->stem_pool = atoi(sp) != 0;
   if (const char *ft = getenv("TSM_CONV_TILE")) e->force_tile = tsm::conv_tile_from_name(ft);
   if (const char *fc = getenv("TSM_CONV_CODE")) e->force_code = atoi(fc);
+  if (const char *f23 = getenv("TSM_FUSE_CONV23")) e->fuse23 = atoi(f23) != 0;
   if (const char *tc = getenv("TSM_TUNE_CACHE")) {
     hipDeviceProp_t prop;
     e->tune_path = tc;
@@ -532,7 +572,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
                   (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess ? std::string(prop.gcnArchName) : "?") +
                   " T" + std::to_string(cfg->num_segments) + " " + std::to_string(cfg->height) + "x" +
                   std::to_string(cfg->width) + " dtype" + std::to_string(cfg->dtype) + " shift" +
-                  std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0);
+                  std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0) + "/" + std::to_string(e->fuse23);
   }
   build_topology(e);
   st = hipSetDevice(cfg->device_id);
@@ -640,6 +680,19 @@ int tsm_finalize(tsm_engine *e) {
     if (rcf) return rcf;
     TSM_HIP(e, hipMemcpy(blk.d_wf, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice));
     TSM_HIP(e, hipMemcpy(blk.d_bf, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  // Blocks without a downsample branch whose mid tensor is 64 / 128 channels wide: conv3's weights once more, in the
+  // fragment order of the fused conv2 + conv3 kernel (fp32 engines).
+  for (Block &blk : e->blocks) {
+    const ConvLayer &c2 = e->convs[blk.conv2], &c3 = e->convs[blk.conv3];
+    if (e->prec != tsm::kPrecF32 || blk.down >= 0 || blk.stride != 1 || (c2.cout != 64 && c2.cout != 128)) continue;
+    std::vector<float> w3f;
+    pack_w3_fragments(host_wp[blk.conv3].data(), c2.cout, &w3f);
+    int rcw = dev_alloc(e, &blk.d_w3f, w3f.size());
+    if (rcw) return rcw;
+    TSM_HIP(e, hipMemcpy(blk.d_w3f, w3f.data(), w3f.size() * sizeof(float), hipMemcpyHostToDevice));
+    blk.cmid = c2.cout;
+    (void)c3;
   }
   host_wp.clear();
   host_bias.clear();

@@ -106,8 +106,26 @@ inline int tile_bucket(int n_clips) {
 }
 
 
+// conv3 weights of a fused conv2+conv3 block (conv23_fused_kernel) in MFMA-fragment order.  w3p is the packed,
+// BN-folded matrix [4 * cmid][cmid]; the kernel's wave `wn` (of cmid / 32) loads, for output chunk j (of 4, cmid
+// channels each) and k-group kk (of cmid / 8), ONE 16-byte element per lane:
+//   out[(((j * wgn + wn) * nkk + kk) * 64 + lane) * 4 + s] = W3[n = j * cmid + wn * 32 + (lane & 31)][k = 8 kk + 4 (lane >> 5) + s]
+// i.e. exactly the B operand of v_mfma_f32_32x32x2_f32 step s of that k-group, so the load is lane-linear (coalesced).
+inline void pack_w3_fragments(const float *w3p, int cmid, std::vector<float> *out) {
+  const int wgn = cmid / 32, nkk = cmid / 8;
+  out->assign((size_t)4 * cmid * cmid, 0.f);
+  for (int j = 0; j < 4; ++j)
+    for (int wn = 0; wn < wgn; ++wn)
+      for (int kk = 0; kk < nkk; ++kk)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int s = 0; s < 4; ++s) {
+            const int n = j * cmid + wn * 32 + (lane & 31), k = 8 * kk + 4 * (lane >> 5) + s;
+            (*out)[((((size_t)j * wgn + wn) * nkk + kk) * 64 + lane) * 4 + s] = w3p[(size_t)n * cmid + k];
+          }
+}
+
 // One line of a TSM_TUNE_CACHE file: "<signature>|<bucket>|c0,c1,...".  Succeeds only when the line starts with
-// `want`, holds exactly codes->size() integers and each is a ConvTile below `num_tiles`, optionally | 0x100 (split-K).
+// `want`, holds exactly codes->size() integers and each is a ConvTile below `num_tiles`, optionally | 0x100 (split-K) | 0x400 (block runs conv2 + conv3 fused).
 // Anything else (foreign keys, truncated lines, garbage, overlong numbers) leaves *codes untouched.
 inline bool parse_tune_line(const char *line, const std::string &want, int num_tiles, std::vector<int> *codes) {
   if (strncmp(line, want.c_str(), want.size()) != 0) return false;
@@ -117,7 +135,7 @@ inline bool parse_tune_line(const char *line, const std::string &want, int num_t
     char *end = nullptr;
     const long v = strtol(q, &end, 10);
     if (end == q) return false;
-    if (v < 0 || (v & ~0x10FL) != 0 || (int)(v & 15) >= num_tiles) return false;
+    if (v < 0 || (v & ~0x50FL) != 0 || (int)(v & 15) >= num_tiles) return false;
     got.push_back((int)v);
     if (*end == ',') q = end + 1;
     else if (*end == '\n' || *end == 0) q = end;

@@ -874,6 +874,228 @@ hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// conv23_fused: Bottleneck.conv2 (3x3, stride 1) + bn2 + ReLU + conv3 (1x1) + bn3 + residual + ReLU in ONE kernel,
+// for the blocks whose mid tensor is the whole K of conv3 (CMID = 64: layer1, CMID = 128: layer2; fp32).
+//
+// A workgroup owns 64 output pixels.  Phase A is the 3x3 implicit GEMM of conv_igemm's fp32 64x64 pipeline
+// (register-resident K-step, one LDS buffer, segmented K where the layer is segmented) over ALL CMID output
+// channels: 2 x (CMID / 32) waves, one 32x32 accumulator tile each.  Phase B turns the accumulators into the
+// tensor the un-fused path would have stored -- relu(acc + bias2) -- but keeps it in LDS ([64][CMID + 4] fp32).
+// Phase C multiplies that tile by W3 in four chunks of BNC = CMID output channels: the A fragments come from the
+// LDS tile, the B fragments straight from global memory (W3 is pre-packed on the host in fragment order, so a
+// wave's fragment load is one fully coalesced 1-KiB read of an L2-resident 64 / 256 KB matrix: no LDS staging for
+// W3), and each chunk ends in conv_igemm's epilogue (LDS transpose, + bias3, + residual, ReLU, 16-byte stores).
+// The CMID-channel mid tensor -- 205 MB per layer1 block at batch 32 -- is never written or re-read, and the
+// HBM-bound (layer1) / prologue-bound (layer2, K = 128) conv3 launch disappears.
+//
+// Every product enters its accumulator in the same order as in the two separate kernels (same k order, same
+// segment sums, same epilogue arithmetic), so the output is bit-identical to them.
+// ---------------------------------------------------------------------------------------------
+template <int CMID>
+__global__ void __launch_bounds__(128 * (CMID / 32)) conv23_fused_kernel(const Fused23Params p) {
+  constexpr int WGN = CMID / 32;         // waves along the CMID channels (phase A) / along a chunk (phase C)
+  constexpr int NT = 128 * WGN;          // 2 x WGN waves
+  constexpr int LRP = NT / 8;            // loader rows per pass
+  constexpr int APASS = 64 / LRP, BPASS = CMID / LRP;
+  constexpr int NITEMS = APASS + BPASS;
+  constexpr int TLD = CMID + 4;          // row stride of the mid tile / of the epilogue staging (floats)
+  constexpr int BNC = CMID;              // output channels per phase-C chunk
+  constexpr int NCHUNK = 4;              // Cout3 = 4 * CMID
+  constexpr int R0 = (64 + CMID) * kLds > 64 * TLD ? (64 + CMID) * kLds : 64 * TLD;
+  __shared__ __attribute__((aligned(16))) float smem[R0 + 64 * TLD];
+  float *Ts = smem + R0;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int m0 = tile * 64;
+
+  const int HW = p.H * p.W;
+  const int frame0 = m0 / HW;
+  const int frame_bytes = HW * CMID * 4;
+  const size_t a_bytes = ((size_t)p.N - frame0) * frame_bytes;
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)frame0 * frame_bytes), 0,
+      (int)(a_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : a_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w2), 0, CMID * 9 * CMID * 4, 0x00020000);
+
+  const int lrow = tid >> 3, chunk = tid & 7;
+  unsigned a_off[APASS], a_mask[APASS], b_off[BPASS];
+#pragma unroll
+  for (int pp = 0; pp < APASS; ++pp) {
+    const int m = m0 + lrow + LRP * pp;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : m0;
+    const int n = mm / HW, rem = mm - n * HW;
+    const int oy = rem / p.W, ox = rem - oy * p.W;
+    a_off[pp] = (unsigned)((n - frame0) * frame_bytes + ((oy - 1) * p.W + (ox - 1)) * CMID * 4 + chunk * 16);
+    unsigned mask = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        if ((unsigned)(oy - 1 + ky) < (unsigned)p.H && (unsigned)(ox - 1 + kx) < (unsigned)p.W) mask |= 1u << (ky * 3 + kx);
+    a_mask[pp] = ok ? mask : 0u;
+  }
+#pragma unroll
+  for (int pp = 0; pp < BPASS; ++pp) b_off[pp] = (unsigned)((lrow + LRP * pp) * 9 * CMID * 4 + chunk * 16);
+
+  f32x4 ra[APASS], rb[BPASS];
+  const int nk = 9 * CMID / kBK;
+  auto gload_item = [&](int kt, int item) {
+    const unsigned dead = (~(unsigned)((kt - nk) >> 31)) & kInvalid;   // K-steps past the end read zeros
+    if (item < APASS) {
+      const int tap = (kt * kBK) / CMID;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const unsigned tap_off = (unsigned)(((ky * p.W + kx) * CMID + (kt * kBK - tap * CMID)) * 4);
+      ra[item] = buf_load4(rsrcA, (((a_mask[item] >> tap) & 1u) ? a_off[item] + tap_off : kInvalid) | dead, 0);
+    } else {
+      rb[item - APASS] = buf_load4(rsrcB, b_off[item - APASS] | dead, (unsigned)kt * (kBK * 4));
+    }
+  };
+  auto lstore_item = [&](int item) {
+    if (item < APASS)
+      *reinterpret_cast<f32x4 *>(smem + (lrow + LRP * item) * kLds + chunk * 4) = ra[item];
+    else
+      *reinterpret_cast<f32x4 *>(smem + (64 + lrow + LRP * (item - APASS)) * kLds + chunk * 4) = rb[item - APASS];
+  };
+
+  // residual / output window of this workgroup: rows m0 .., all 4 * CMID channels (rows past M are dropped / zero)
+  const int cout = NCHUNK * BNC;
+  const size_t y_bytes = ((size_t)p.M - m0) * cout * 4;
+  const int y_rec = (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes);
+  const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(p.res + (size_t)m0 * cout), 0, y_rec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)m0 * cout, 0, y_rec, 0x00020000);
+
+  // ---- phase A: 3x3 conv, K = 9 * CMID, register-resident K-step pipeline -------------------------------
+  f32x16 acc, tot;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = tot[e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < NITEMS; ++it) gload_item(0, it);
+#pragma unroll
+  for (int it = 0; it < NITEMS; ++it) lstore_item(it);
+#pragma unroll
+  for (int it = 0; it < NITEMS; ++it) gload_item(1, it);
+  __syncthreads();
+  const bool seg = p.kseg_len > 0;
+  const int seg_len = seg ? p.kseg_len : 0x3fffffff;
+  f32x4 ra_[4], rb_[4];
+  for (int kt = 0; kt < nk;) {
+    const int kend = kt + seg_len < nk ? kt + seg_len : nk;
+    for (; kt < kend; ++kt) {
+      {
+        const float *As = smem + (wm * 32 + l31) * kLds + half * 4;
+        const float *Bs = smem + (64 + wn * 32 + l31) * kLds + half * 4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          ra_[kk] = *reinterpret_cast<const f32x4 *>(As + kk * 8);
+          rb_[kk] = *reinterpret_cast<const f32x4 *>(Bs + kk * 8);
+        }
+      }
+      __syncthreads();  // every wave holds its fragments: the buffer may be overwritten
+      int cnt = 0;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra_[kk][s4], rb_[kk][s4], acc, 0, 0, 0);
+          ++cnt;
+          const int done = cnt < 12 ? (cnt * 2 * NITEMS) / 12 : 2 * NITEMS;
+          const int before = cnt - 1 < 12 ? ((cnt - 1) * 2 * NITEMS) / 12 : 2 * NITEMS;
+#pragma unroll
+          for (int it = before; it < done; ++it) {
+            if (it < NITEMS) lstore_item(it);
+            else gload_item(kt + 2, it - NITEMS);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      __syncthreads();  // tile kt+1 is complete in LDS
+    }
+    if (seg) {          // out = ((0 + s0) + s1) + ..., exactly as conv_igemm<SEG> sums its segments
+      tot += acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    }
+  }
+
+  // ---- phase B: the mid tensor tile, as the un-fused conv2 would have stored it, into LDS -----------------
+  {
+    const float b2 = p.bias2[wn * 32 + l31];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      Ts[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * TLD + wn * 32 + l31] = fmaxf((seg ? tot[e] : acc[e]) + b2, 0.f);
+  }
+  __syncthreads();
+
+  // ---- phase C: [64 x CMID] x W3^T in NCHUNK chunks of BNC output channels ---------------------------------
+  constexpr int NKK = CMID / 8;          // 8-deep k-groups of conv3
+  constexpr int TPR = BNC / 4, RPP = NT / TPR, EPASS = 64 / RPP;
+  const int ecol = (tid % TPR) * 4, erow = tid / TPR;
+  const f32x4 *w3f = reinterpret_cast<const f32x4 *>(p.w3f);
+  f32x4 bfrag[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) bfrag[kk] = w3f[((0 * WGN + wn) * NKK + kk) * 64 + lane];
+  const float *Ta = Ts + (wm * 32 + l31) * TLD + half * 4;
+  float *Cs = smem;
+#pragma unroll 1
+  for (int j = 0; j < NCHUNK; ++j) {
+    f32x4 rres[EPASS];
+#pragma unroll
+    for (int k = 0; k < EPASS; ++k)
+      rres[k] = buf_load4(rsrcR, (unsigned)(((erow + k * RPP) * cout + j * BNC + ecol) * 4), 0);
+    f32x16 c3;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c3[e] = 0.f;
+    const int jn = j + 1 < NCHUNK ? j + 1 : j;   // (the last chunk re-fetches its own fragments: branch-free)
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(Ta + kk * 8);
+      const f32x4 b = bfrag[kk];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b[s4], c3, 0, 0, 0);
+      bfrag[kk] = w3f[((jn * WGN + wn) * NKK + kk) * 64 + lane];   // next chunk's fragment: a whole chunk to land
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+      Cs[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * TLD + wn * 32 + l31] = c3[e];
+    __syncthreads();
+    const f32x4 bias = *reinterpret_cast<const f32x4 *>(p.bias3 + j * BNC + ecol);
+#pragma unroll
+    for (int k = 0; k < EPASS; ++k) {
+      const int rr = erow + k * RPP;
+      f32x4 v = *reinterpret_cast<const f32x4 *>(Cs + rr * TLD + ecol);
+      v += bias;
+      v += rres[k];
+      v[0] = fmaxf(v[0], 0.f);
+      v[1] = fmaxf(v[1], 0.f);
+      v[2] = fmaxf(v[2], 0.f);
+      v[3] = fmaxf(v[3], 0.f);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcY,
+                                             (int)((rr * cout + j * BNC + ecol) * 4), 0, 0);
+    }
+    __syncthreads();   // the staging tile is free for the next chunk
+  }
+}
+
+hipError_t launch_conv23_fused(const Fused23Params &p_in, int cmid, hipStream_t s) {
+  Fused23Params p = p_in;
+  if (!p.x || !p.w2 || !p.bias2 || !p.w3f || !p.bias3 || !p.res || !p.y) return hipErrorInvalidValue;
+  if ((cmid != 64 && cmid != 128) || p.N <= 0 || p.H <= 0 || p.W <= 0 || p.M != p.N * p.H * p.W) return hipErrorInvalidValue;
+  if (p.kseg_len < 0 || 6.0 * p.H * p.W * cmid * 4.0 > 2.0e9) return hipErrorInvalidValue;   // 32-bit offsets per window
+  const unsigned grid = (unsigned)((p.M + 63) / 64);
+  if (cmid == 64) hipLaunchKernelGGL(conv23_fused_kernel<64>, dim3(grid), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(conv23_fused_kernel<128>, dim3(grid), dim3(512), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // stem_direct: the 7x7 stride-2 stem of the bf16 formats as a direct convolution from an LDS-resident input patch.
 // The generic implicit-GEMM loader gathers 28 groups of 8 elements per output pixel from L2 (each input pixel pair
 // is fetched ~12 times): with 3 input channels that gather, not the MFMA or HBM, bounds the stem in these formats.

@@ -204,7 +204,9 @@ class TsmEngine:
         clips = _as_f32(clips)
         self._check_clips(clips.size, clips.shape[0], _lib.LAYOUT_NTCHW)
         n = clips.shape[0] * self.num_segments
-        cap = n * max(((self.height + 1) // 2) * ((self.width + 1) // 2) * 64, self.height * self.width * 8)
+        h1, w1 = (self.height - 1) // 2 + 1, (self.width - 1) // 2 + 1          # stem conv output
+        hp, wp = (h1 - 1) // 2 + 1, (w1 - 1) // 2 + 1                            # after the max-pool = layer1's size
+        cap = n * max(h1 * w1 * 64, hp * wp * 256, self.height * self.width * 8)
         buf = np.empty(cap, dtype=np.float32)
         shape = (C.c_int64 * 4)()
         _lib.check(self._lib.tsm_forward_tap(self._h, clips.ctypes.data, _lib.MEM_HOST, _lib.LAYOUT_NTCHW,
@@ -228,8 +230,9 @@ class TsmEngine:
     @classmethod
     def tile_name(cls, code: int) -> str:
         """``tile + 256 * split``: '64x64/splitK' = one workgroup per (tile, K segment), combined in segment order
-        (segmented fp32 layers at small batch)."""
-        return cls.TILE_NAMES[code & 15] + ('/splitK' if code >> 8 else '')
+        (segmented fp32 layers at small batch); '+conv3' on a block's conv2 = conv2 + conv3 + residual run as one fused
+        kernel (the conv3 entry of that block is then unused)."""
+        return cls.TILE_NAMES[code & 15] + ('/splitK' if code & 0x100 else '') + ('+conv3' if code & 0x400 else '')
 
     def conv_tiles(self, n_clips: int) -> Dict[str, str]:
         """Tile shape the autotuner chose per conv launch for an ``n_clips`` forward."""
