@@ -45,10 +45,11 @@ enum ConvPrec { kPrecF32 = 0, kPrecBf16x3 = 1, kPrecBf16 = 2 };
 enum ConvTile {
   kTileAuto = 0, kTile128x128 = 1, kTile128x64 = 2, kTile64x64 = 3, kTile32x32 = 4,
   kTile128x128w8 = 5,  // 128x128 on 8 waves (512 threads): same LDS as kTile128x128, twice the waves per SIMD
-  kNumTiles = 6
+  kTile256x256 = 6,    // conv_bf16_256_kernel: bf16 only, 8 waves, one workgroup per CU, operands by LDS-DMA
+  kNumTiles = 7
 };
 void conv_tile_dims(int tile, int *bm, int *bn);
-// "128x128" | "128x64" | "64x64" | "32x32" | "128x128w8" -> ConvTile (kTileAuto for anything else).
+// "128x128" | "128x64" | "64x64" | "32x32" | "128x128w8" | "256x256" -> ConvTile (kTileAuto for anything else).
 int conv_tile_from_name(const char *name);
 // Is `tile` usable for this problem (Cout divisibility)?
 bool conv_tile_valid(const ConvParams &p, int tile);

@@ -798,7 +798,7 @@ void conv_tile_shape(const ConvParams &p, int *bm, int *bn) {
 int conv_tile_from_name(const char *name) {
   if (!name) return kTileAuto;
   static const struct { const char *n; int t; } names[] = {{"128x128", kTile128x128}, {"128x64", kTile128x64},
-      {"64x64", kTile64x64}, {"32x32", kTile32x32}, {"128x128w8", kTile128x128w8}};
+      {"64x64", kTile64x64}, {"32x32", kTile32x32}, {"128x128w8", kTile128x128w8}, {"256x256", kTile256x256}};
   for (const auto &e : names)
     if (strcmp(name, e.n) == 0) return e.t;
   return kTileAuto;
@@ -811,14 +811,18 @@ bool conv_tile_valid(const ConvParams &p, int tile) {
     case kTile64x64: return p.Cout % 64 == 0;
     case kTile32x32: return p.Cout % 32 == 0 && p.prec == kPrecF32;  // single-wave tiles: fp32 only
     case kTile128x128w8: return p.Cout % 128 == 0;
+    case kTile256x256:   // (ks is checked at launch: the stem has C == 4 and never qualifies)
+      return p.prec == kPrecBf16 && p.Cout % 256 == 0 && p.C % 64 == 0 && !p.res && !p.x2;
     default: return false;
   }
 }
 
 void conv_tile_dims(int tile, int *bm, int *bn) {
-  *bm = tile == kTile32x32 ? 32 : (tile == kTile64x64 ? 64 : 128);
-  *bn = tile == kTile32x32 ? 32 : ((tile == kTile128x128 || tile == kTile128x128w8) ? 128 : 64);
+  *bm = tile == kTile256x256 ? 256 : tile == kTile32x32 ? 32 : (tile == kTile64x64 ? 64 : 128);
+  *bn = tile == kTile256x256 ? 256 : tile == kTile32x32 ? 32 : ((tile == kTile128x128 || tile == kTile128x128w8) ? 128 : 64);
 }
+
+static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s);
 
 template <int KS, bool SHIFT, bool RES>
 static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
@@ -828,6 +832,10 @@ static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
   if (p.tile != kTileAuto) {
     if (!conv_tile_valid(p, p.tile)) return hipErrorInvalidValue;
     conv_tile_dims(p.tile, &bm, &bn);
+  }
+  if (p.tile == kTile256x256) {
+    if constexpr (KS != 7 && !RES) return launch_conv_bf16_256(p, KS, s);
+    else return hipErrorInvalidValue;
   }
   if (p.kseg_len > 0 && !(bm == 32 && bn == 32)) {  // segmented accumulation exists on 64x64 / 32x32 tiles only
     bm = 64;
@@ -871,6 +879,240 @@ hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
     case 7: return p.res ? hipErrorInvalidValue : launch_conv_ks<7, false, false>(p, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_bf16_256: the bf16 implicit GEMM on a 256 x 256 tile, ONE 8-wave workgroup per CU, operands staged by LDS-DMA.
+//
+// Why: the 128 x 128 bf16 tiles of conv_igemm are LDS-bound -- per MFMA they need as many LDS-array cycles
+// (VGPR-staged ds_write_b128 of both operands + fragment reads) as the matrix pipe gives, and one barrier + full
+// vmcnt drain per K-step on top (profiles/r01_bf16_pmc_sq_summary.txt: MFMA busy 0.27-0.34).  This kernel is the
+// structure cdna_hip_programming.md prescribes for that regime:
+//   * 256 x 256 output tile, K-tile 64 channels, 8 waves as 2 (M) x 4 (N), 128 x 64 per wave = 4 x 2 MFMA tiles of
+//     v_mfma_f32_32x32x16_bf16: a quarter of the staging bytes and 3/4 of the fragment reads per MFMA of the 128^2 tile;
+//   * both operands go global -> LDS by `buffer_load ... lds` (no VGPR round trip, no ds_write): a wave-instruction
+//     writes 1 KiB = 16 rows x 64 B; the 16-byte chunk a lane fetches is XOR-swizzled on the SOURCE side with
+//     f(row) = (row >> 2) & 3 and the fragment reads apply the same involution: ds_read_b128 is conflict-free;
+//   * a K-tile is cut in four 16-KB "half-operands" by K, not by rows -- {A, B} x {channels 0-31, 32-63} -- because the
+//     four phases of a K-tile each multiply ONE k16 group (6 ds_read_b128 + 8 MFMAs per wave): the k 0-31 halves are
+//     dead after phase 1 and are re-filled (for K-tile t+2) in phases 2 and 3, the k 32-63 halves in phases 0 and 1 of
+//     the next K-tile.  Two 64-KB buffers, FOUR half-operands always in flight, retired by a counted
+//     `s_waitcnt vmcnt(8)` twice per K-tile -- never vmcnt(0) inside the loop -- and raw s_barriers;
+//   * K-tiles past the end of K are staged with an out-of-range offset (zeros, no memory traffic), so the loop and
+//     its wait counts are branch-free.
+// Per output the products enter the accumulator in conv_igemm's order (k16 groups ascending), so results are
+// bit-identical to the other bf16 tiles.  Epilogue: accumulators -> wave-private LDS slab (no workgroup barrier)
+// -> + bias, ReLU, bf16, 16-byte stores of whole 128-byte row segments.
+// Needs Cout % 256 == 0, C % 64 == 0, no residual / second source; the tuner picks it where it wins (long K, at least
+// one tile per CU: conv2 and conv1 of layer3-4 at the config-5 size).
+// ---------------------------------------------------------------------------------------------
+template <int KS, bool SHIFT>
+__global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams p) {
+  static_assert(KS == 1 || KS == 3, "1x1 (optionally temporally shifted) and 3x3");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 buffers x 64 KB; epilogue: 8 x 8704 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  const int HoWo = p.Ho * p.Wo;
+  const int n_first = m0 / HoWo;
+  const int frame0 = SHIFT ? (n_first > 0 ? n_first - 1 : 0) : n_first;
+  const int frame_bytes = p.Hi * p.Wi * p.C * 2;
+  const size_t a_bytes = ((size_t)p.N - frame0) * (size_t)frame_bytes;
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)frame0 * frame_bytes), 0,
+      (int)(a_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : a_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(reinterpret_cast<const char *>(p.w) + (size_t)n0 * p.Kp * 2), 0, 256 * p.Kp * 2, 0x00020000);
+
+  // ---- loader state: this lane fills LDS slot (row, lane & 3) of rows piece * 16 + (lane >> 2), piece = 2 * wave + q
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);      // global 16-B chunk held by that slot (swizzle on the source)
+  unsigned a_off[2], a_offp[SHIFT ? 2 : 1], a_offm[SHIFT ? 2 : 1], a_mask[KS == 3 ? 2 : 1], b_off[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = (2 * wave + q) * 16 + (lane >> 2);
+    const int m = m0 + row;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : m0;
+    const int n = mm / HoWo, rem = mm - n * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+    const int base = (n - frame0) * frame_bytes + (iy0 * p.Wi + ix0) * p.C * 2 + chunk * 16;
+    a_off[q] = (KS == 1 && !ok) ? kInvalid : (unsigned)base;
+    if (KS == 3) {
+      unsigned mask = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          if ((unsigned)(iy0 + ky) < (unsigned)p.Hi && (unsigned)(ix0 + kx) < (unsigned)p.Wi) mask |= 1u << (ky * 3 + kx);
+      a_mask[q] = ok ? mask : 0u;
+    }
+    if (SHIFT) {
+      const int t = n % p.T;
+      a_offp[q] = (ok && t < p.T - 1) ? (unsigned)(base + frame_bytes) : kInvalid;
+      a_offm[q] = (ok && t > 0) ? (unsigned)(base - frame_bytes) : kInvalid;
+    }
+    b_off[q] = (unsigned)(row * p.Kp * 2 + chunk * 16);
+  }
+  const int nt = p.Kp / 64;                               // K-tiles
+  typedef __attribute__((address_space(3))) void lds_void;
+  // Stage one half-operand of K-tile kt: which = 0 A k0-31, 1 B k0-31, 2 A k32-63, 3 B k32-63 (two 1-KiB pieces per wave)
+  auto stage = [&](int kt, int which) {
+    const unsigned dead = (~(unsigned)((kt - nt) >> 31)) & kInvalid;
+    const int kh = which >> 1;
+    const unsigned kbytes = (unsigned)kt * 128u + (unsigned)kh * 64u;
+    unsigned char *dst = lds + (kt & 1) * 65536 + ((which & 1) * 2 + kh) * 16384 + wave * 2048;
+    if (which & 1) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)(dst + q * 1024), 16, (int)(b_off[q] | dead), (int)kbytes, 0, 0);
+    } else if (KS == 1) {
+      unsigned mp = 0u, mm_ = 0u, m0_ = ~0u;
+      if (SHIFT) {
+        const int c = kt * 64 + kh * 32 + chunk * 8;      // first channel of this lane's chunk
+        mp = 0u - (unsigned)(c < p.fold);
+        mm_ = (0u - (unsigned)(c < 2 * p.fold)) & ~mp;
+        m0_ = ~(mp | mm_);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        unsigned off = a_off[q];
+        if (SHIFT) off = (a_offp[q] & mp) | (a_offm[q] & mm_) | (a_off[q] & m0_);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(dst + q * 1024), 16, (int)(off | dead), (int)kbytes, 0, 0);
+      }
+    } else {
+      const int tap = (kt * 64) >> (p.logC4 + 2);         // C >= 64: a K-tile never straddles a tap
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const unsigned tap_off = (unsigned)(((ky * p.Wi + kx) * p.C + (kt * 64 - tap * p.C) + kh * 32) * 2);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(dst + q * 1024), 16,
+                                                 (int)((((a_mask[q] >> tap) & 1u) ? a_off[q] + tap_off : kInvalid) | dead), 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addresses: row * 64 B + swizzled chunk; k16 group g reads chunk 2 * (g & 1) + half of region g >> 1
+  const int sw = (l31 >> 2) & 3;
+  const unsigned a_rd0 = (unsigned)((wm * 128 + l31) * 64 + ((0 + half) ^ sw) * 16);
+  const unsigned a_rd1 = (unsigned)((wm * 128 + l31) * 64 + ((2 + half) ^ sw) * 16);
+  const unsigned b_rd0 = (unsigned)(32768 + (wn * 64 + l31) * 64 + ((0 + half) ^ sw) * 16);
+  const unsigned b_rd1 = (unsigned)(32768 + (wn * 64 + l31) * 64 + ((2 + half) ^ sw) * 16);
+
+  // prologue: the six half-operands the schedule has in flight before K-tile 0 starts
+  stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3); stage(1, 0); stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // K-tile 0, k 0-31 of A and B have landed (this wave's share)
+  __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < nt; ++kt) {
+    const unsigned buf = (unsigned)(kt & 1) * 65536u;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      u32x4 af[4], bf[2];
+      {
+        const unsigned ra = buf + (ph >> 1) * 16384u + ((ph & 1) ? a_rd1 : a_rd0);
+        const unsigned rb = buf + (ph >> 1) * 16384u + ((ph & 1) ? b_rd1 : b_rd0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const u32x4 *>(lds + rb + j * 2048);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4 *>(lds + ra + i * 2048);
+      }
+      // refill what the previous phases have finished reading: k 32-63 halves of the OTHER buffer (K-tile kt+1) in
+      // phases 0-1, k 0-31 halves of THIS buffer (K-tile kt+2) in phases 2-3
+      if (ph == 0) stage(kt + 1, 2);
+      else if (ph == 1) stage(kt + 1, 3);
+      else if (ph == 2) stage(kt + 2, 0);
+      else stage(kt + 2, 1);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]),
+                                                              acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // phases 1 and 3 end with the counted wait that retires the two half-operands the NEXT phase reads
+      if (ph & 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the dead tail stages (zeros) must land before LDS is reused
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: per wave, four 32 x 64 slabs through a private LDS region ---------------------------------
+  float *Cs = reinterpret_cast<float *>(lds + wave * 8704);  // [32][68] fp32
+  const size_t y_bytes = ((size_t)p.M - m0) * p.Cout * 2;
+  const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char *>(p.y) + (size_t)m0 * p.Cout * 2, 0, (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
+  const float floor_ = p.relu ? 0.f : -INFINITY;
+  const int c8 = lane & 7, r8l = lane >> 3;
+  const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 64 + c8 * 8);
+  const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 64 + c8 * 8 + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) Cs[((e & 3) + 8 * (e >> 2) + 4 * half) * 68 + j * 32 + l31] = acc[i][j][e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (same wave wrote it: no barrier needed)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = r8l + 8 * k;
+      const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cs + rr * 68 + c8 * 8);
+      const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cs + rr * 68 + c8 * 8 + 4);
+      u32x4 o;
+      o[0] = pack_bf16(fmaxf(c0[0] + bias0[0], floor_), fmaxf(c0[1] + bias0[1], floor_));
+      o[1] = pack_bf16(fmaxf(c0[2] + bias0[2], floor_), fmaxf(c0[3] + bias0[3], floor_));
+      o[2] = pack_bf16(fmaxf(c1[0] + bias1[0], floor_), fmaxf(c1[1] + bias1[1], floor_));
+      o[3] = pack_bf16(fmaxf(c1[2] + bias1[2], floor_), fmaxf(c1[3] + bias1[3], floor_));
+      const int row = wm * 128 + i * 32 + rr;
+      __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (row * p.Cout + n0 + wn * 64 + c8 * 8) * 2, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slab reads done before the next slab overwrites it
+  }
+}
+
+bool conv_bf16_256_valid(const ConvParams &p, int ks) {
+  return p.prec == kPrecBf16 && (ks == 1 || ks == 3) && p.Cout % 256 == 0 && p.C % 64 == 0 && p.Kp % 64 == 0 && !p.res &&
+         !p.x2 && p.kseg_len == 0 && (ks == 1 || p.T == 0);
+}
+
+static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s) {
+  if (!conv_bf16_256_valid(p, ks)) return hipErrorInvalidValue;
+  p.ntm = (p.M + 255) / 256;
+  p.ntn = p.Cout / 256;
+  const dim3 grid((unsigned)(p.ntm * p.ntn)), block(512);
+  constexpr size_t kLdsBytes = 131072;
+  static bool attr_set = false;
+  if (!attr_set) {   // above the 64 KB default: opt in once per kernel (idempotent; races only repeat the same call)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    attr_set = true;
+  }
+  if (ks == 3) hipLaunchKernelGGL((conv_bf16_256_kernel<3, false>), grid, block, kLdsBytes, s, p);
+  else if (p.T > 0) hipLaunchKernelGGL((conv_bf16_256_kernel<1, true>), grid, block, kLdsBytes, s, p);
+  else hipLaunchKernelGGL((conv_bf16_256_kernel<1, false>), grid, block, kLdsBytes, s, p);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
