@@ -898,6 +898,8 @@ hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
 //     dead after phase 1 and are re-filled (for K-tile t+2) in phases 2 and 3, the k 32-63 halves in phases 0 and 1 of
 //     the next K-tile.  Two 64-KB buffers, FOUR half-operands always in flight, retired by a counted
 //     `s_waitcnt vmcnt(8)` twice per K-tile -- never vmcnt(0) inside the loop -- and raw s_barriers;
+//   * the two waves of a SIMD run STAGGERED by one barrier (waves 4-7 behind waves 0-3): one is in its 8-MFMA cluster
+//     while the other reads fragments and issues DMA, instead of both queueing on the matrix pipe together;
 //   * K-tiles past the end of K are staged with an out-of-range offset (zeros, no memory traffic), so the loop and
 //     its wait counts are branch-free.
 // Per output the products enter the accumulator in conv_igemm's order (k16 groups ascending), so results are
@@ -1018,6 +1020,14 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams 
   stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3); stage(1, 0); stage(1, 1);
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // K-tile 0, k 0-31 of A and B have landed (this wave's share)
   __builtin_amdgcn_s_barrier();
+  // Stagger: waves 4-7 (wm == 1; the second wave of every SIMD) run one barrier behind waves 0-3, so that on each
+  // SIMD one wave is in its MFMA cluster while its partner reads fragments / issues DMA -- in lockstep both would
+  // read together and then queue on the one matrix pipe (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+  // Consequences for the hand-placed synchronisation: (a) the counted vmcnt sits BEFORE the first barrier of the odd
+  // phases, so that the delayed group too has retired its DMA one barrier before the early group reads the data;
+  // (b) the fragment reads are retired (lgkmcnt(0)) before the first barrier of their phase, so that the DMA which the
+  // early group issues one phase later cannot overtake a read of the delayed group.
+  if (wm == 1) __builtin_amdgcn_s_barrier();
 
   for (int kt = 0; kt < nt; ++kt) {
     const unsigned buf = (unsigned)(kt & 1) * 65536u;
@@ -1038,9 +1048,12 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams 
       else if (ph == 1) stage(kt + 1, 3);
       else if (ph == 2) stage(kt + 2, 0);
       else stage(kt + 2, 1);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // odd phases: the counted wait that retires the two half-operands the NEXT phase reads (8 = the four younger
+      // half-operands x 2 pieces per wave stay in flight; never 0 inside the loop)
+      if (ph & 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -1050,11 +1063,10 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams 
                                                               acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      // phases 1 and 3 end with the counted wait that retires the two half-operands the NEXT phase reads
-      if (ph & 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
   }
+  if (wm == 0) __builtin_amdgcn_s_barrier();              // the early group waits for the delayed one
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the dead tail stages (zeros) must land before LDS is reused
   __builtin_amdgcn_s_barrier();
 
