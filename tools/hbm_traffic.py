@@ -3,11 +3,20 @@
 so the read side is doubled.  Prints per-kernel totals of the last forward and the per-launch average
 for the dominant kernel.
 
-    python tools/hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv>
+    python tools/hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> "<dominant kernel>" \
+        [--update-json clips_per_gpu num_segments height width]
+
+``--update-json`` writes the result into profiles/traffic.json, stamped with the sha of csrc/ it was measured on
+(workoutdetector_amd.build.csrc_sha16): bench.py only reports a traffic figure whose stamp matches the current source.
 """
 import csv
+import json
+import os
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def load(path, counter):
@@ -26,7 +35,7 @@ def last_forward(per, names):
     return [d for d in ids if packs[-2] <= d < packs[-1]]
 
 
-def main(fetch_csv, write_csv, dominant='conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, 1, true>'):
+def main(fetch_csv, write_csv, dominant='conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, true>'):
     f, fn = load(fetch_csv, 'FETCH_SIZE')
     w, wn = load(write_csv, 'WRITE_SIZE')
     # The two passes are separate processes and the engine's tile autotuner may pick a different shape for
@@ -46,5 +55,33 @@ def main(fetch_csv, write_csv, dominant='conv_igemm<64, 64, 2, 2, 3, false, fals
     return (tot_r + tot_w), per_launch
 
 
+def update_json(kernel, config, forward_bytes, per_launch, note):
+    from workoutdetector_amd.build import csrc_sha16
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        d = {'entries': []}
+    b, t, h, w = config
+    cfg = dict(clips_per_gpu=b, num_segments=t, height=h, width=w)
+    d['entries'] = [e for e in d['entries'] if not (e.get('config') == cfg and e.get('kernel') == kernel)]
+    d['entries'].append(dict(config=cfg, kernel=kernel, hbm_bytes_per_launch=per_launch, forward_hbm_bytes=forward_bytes,
+                             csrc_sha16=csrc_sha16(), method=note))
+    json.dump(d, open(path, 'w'), indent=1)
+    print('profiles/traffic.json updated for', kernel, cfg)
+
+
 if __name__ == '__main__':
-    main(*sys.argv[1:4])
+    args = sys.argv[1:]
+    upd = None
+    if '--update-json' in args:
+        i = args.index('--update-json')
+        upd = [int(v) for v in args[i + 1:i + 5]]
+        args = args[:i]
+    total, per_launch = main(*args[:3])
+    if upd:
+        update_json(args[2], upd, total, per_launch,
+                    'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_traffic.sh) over '
+                    '`bench.py --steps 2 --warmup 2 --no-alt --no-cpu-baseline ...`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 '
+                    "(gfx950 FETCH_SIZE halves wide coalesced reads, MI355X_MICROARCH.md 'HBM'); per-launch = average over "
+                    'the launches of this kernel in the last forward')

@@ -36,26 +36,49 @@ def main(path, frames=256, size=224):
             convs[-1]['End_Timestamp'] = int(convs[-1]['End_Timestamp']) + int(r['End_Timestamp']) - int(r['Start_Timestamp'])
             convs[-1]['Kernel_Name'] = convs[-1]['Kernel_Name'].replace('>', ' +reduce>', 1)
     byname = {r['name']: r for r in layer_table(size, size)}
-    order = ['conv1']
-    fused = len(convs) == 49          # conv3 + downsample of each stage's first block run as one launch
+    # Expected launch order, consumed against the trace: the stem; per block [downsample,] conv1, then either conv2 and
+    # conv3 (the latter fused with the downsample branch in a stage's first block) or ONE conv23_fused launch.
+    def _dual(name):      # conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, PREC, DUAL, SEG>
+        args = [a.strip() for a in name.split('<')[1].split('>')[0].split(',')] if 'conv_igemm<' in name else []
+        return len(args) > 8 and args[8] == 'true'
+    n_down = sum(_dual(r['Kernel_Name']) for r in convs)
+    rows, it = [], iter(convs)
+
+    def take(names):
+        r = next(it, None)
+        if r is not None:
+            rows.append(('+'.join(n.split('.')[-1] if i else n for i, n in enumerate(names)), names, r))
+        return r
+
+    take(['conv1'])
     for li, nb in enumerate((3, 4, 6, 3), 1):
         for b in range(nb):
             p = f'layer{li}.{b}'
-            if b == 0 and not fused:
-                order.append(p + '.downsample')
-            order += [p + '.conv1', p + '.conv2', p + '.conv3' + ('+downsample' if (b == 0 and fused) else '')]
-    if len(order) != len(convs):
-        print('launch count', len(convs), 'differs from layer count', len(order))
+            separate_down = b == 0 and n_down == 0
+            if separate_down:
+                take([p + '.downsample'])
+            take([p + '.conv1'])
+            nxt = next(it, None)
+            if nxt is None:
+                break
+            if 'conv23_fused' in nxt['Kernel_Name']:
+                rows.append((p + '.conv2+conv3', [p + '.conv2', p + '.conv3'], nxt))
+                continue
+            rows.append((p + '.conv2', [p + '.conv2'], nxt))
+            take([p + '.conv3'] + ([p + '.downsample'] if (b == 0 and not separate_down) else []))
+    if next(it, None) is not None or len(rows) != len(convs):
+        print('launch count', len(convs), 'does not match the expected schedule: rows below may be misaligned')
     tot = totf = 0.0
-    for nm, r in zip(order, convs):
+    for nm, parts, r in rows:
         dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-        fl = 2 * frames * (byname[nm]['macs'] if '+' not in nm else
-                           byname[nm.split('+')[0]]['macs'] + byname[nm.split('.conv3')[0] + '.downsample']['macs'])
+        fl = 2 * frames * sum(byname[q]['macs'] for q in parts)
         tot += dur
         totf += fl
         kn = r['Kernel_Name'].split('<')[1].split('>')[0] if '<' in r['Kernel_Name'] else r['Kernel_Name'][:30]
+        if 'conv23_fused' in r['Kernel_Name'] or 'conv_bf16_256' in r['Kernel_Name']:
+            kn = r['Kernel_Name'].split('tsm::')[-1].split('(')[0]
         grid = int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))
-        print(f"{nm:22s} {kn:20s} wgs={grid:6d} {dur:8.1f}us {fl / dur / 1e6:7.1f} TF/s  vgpr={r.get('VGPR_Count','?')}")
+        print(f"{nm:26s} {kn:44s} wgs={grid:6d} {dur:8.1f}us {fl / dur / 1e6:7.1f} TF/s  vgpr={r.get('VGPR_Count','?')}")
     span = (int(fw[-1]['End_Timestamp']) - int(fw[0]['Start_Timestamp'])) / 1e3
     print(f'sum conv {tot:.1f} us = {totf / tot / 1e6:.1f} TF/s; forward span {span:.1f} us; '
           f'other kernels {sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in fw if "conv_" not in r["Kernel_Name"] and "stem_" not in r["Kernel_Name"] and "splitk_reduce" not in r["Kernel_Name"]):.1f} us')

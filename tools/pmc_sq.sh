@@ -4,8 +4,9 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=$1; shift
+(cd $R && python3 -m workoutdetector_amd.build > /dev/null)   # never let bench.py compile under the profiler
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES \
+rocprofv3 --pmc ${PMC:-GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES} \
   --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq_$tag -o run -- \
   python3 $R/bench.py --steps 2 --warmup 2 --no-alt --no-cpu-baseline "$@" > $R/gpurun_out/pmc_sq_$tag.log 2>&1
 cd $R

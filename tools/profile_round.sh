@@ -3,12 +3,13 @@
 #   bash tools/profile_round.sh   (from the repo root; writes gpurun_out/final_*; copy the summaries into profiles/)
 set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+(cd $R && python3 -m workoutdetector_amd.build > /dev/null)   # never let bench.py compile under the profiler
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final_stats -o run -- \
   python3 $R/bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline > $R/gpurun_out/final_stats_bench.json 2> $R/gpurun_out/final_stats.log
 cd $R
 python3 tools/layer_times.py gpurun_out/final_stats/run_kernel_trace.csv 256 > gpurun_out/final_per_layer.txt
-DOMINANT="conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, 1, true>" bash tools/pmc_traffic.sh f32 > gpurun_out/final_traffic_f32.txt 2>&1
+DOMINANT="conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, true>" UPDATE="32 8 224 224" bash tools/pmc_traffic.sh f32 > gpurun_out/final_traffic_f32.txt 2>&1
 tail -3 gpurun_out/final_per_layer.txt
 cat gpurun_out/final_traffic_f32.txt
 tail -1 gpurun_out/final_stats_bench.json | head -c 600
