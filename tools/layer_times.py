@@ -30,7 +30,7 @@ def main(path, frames=256, size=224):
     # a split-K layer is two launches: the conv and its splitk_reduce, whose time is added to the conv's row
     convs = []
     for r in fw:
-        if 'conv_' in r['Kernel_Name'] or 'stem_' in r['Kernel_Name']:      # stem_direct / stem_pool = conv1 (+ max-pool)
+        if 'conv' in r['Kernel_Name'] or 'stem_' in r['Kernel_Name']:      # stem_direct / stem_pool = conv1 (+ max-pool)
             convs.append(dict(r))
         elif 'splitk_reduce' in r['Kernel_Name'] and convs:
             convs[-1]['End_Timestamp'] = int(convs[-1]['End_Timestamp']) + int(r['End_Timestamp']) - int(r['Start_Timestamp'])
@@ -76,12 +76,12 @@ def main(path, frames=256, size=224):
         totf += fl
         kn = r['Kernel_Name'].split('<')[1].split('>')[0] if '<' in r['Kernel_Name'] else r['Kernel_Name'][:30]
         if 'conv23_fused' in r['Kernel_Name'] or 'conv_bf16_256' in r['Kernel_Name']:
-            kn = r['Kernel_Name'].split('tsm::')[-1].split('(')[0]
+            kn = r['Kernel_Name'].split('tsm::')[1].split('(')[0]
         grid = int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))
         print(f"{nm:26s} {kn:44s} wgs={grid:6d} {dur:8.1f}us {fl / dur / 1e6:7.1f} TF/s  vgpr={r.get('VGPR_Count','?')}")
     span = (int(fw[-1]['End_Timestamp']) - int(fw[0]['Start_Timestamp'])) / 1e3
     print(f'sum conv {tot:.1f} us = {totf / tot / 1e6:.1f} TF/s; forward span {span:.1f} us; '
-          f'other kernels {sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in fw if "conv_" not in r["Kernel_Name"] and "stem_" not in r["Kernel_Name"] and "splitk_reduce" not in r["Kernel_Name"]):.1f} us')
+          f'other kernels {sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in fw if "conv" not in r["Kernel_Name"] and "stem_" not in r["Kernel_Name"] and "splitk_reduce" not in r["Kernel_Name"]):.1f} us')
 
 
 if __name__ == '__main__':

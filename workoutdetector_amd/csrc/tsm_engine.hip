@@ -418,16 +418,20 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     if (want("stem")) return hit(cur, n, e->hp, e->wp, 64);
   }
   int h = e->hp, w = e->wp;
-  int li = 0, bi = 0;
-  for (size_t k = 0; k < e->blocks.size(); ++k) {
+  std::vector<std::string> block_names;
+  for (int li = 0; li < 4; ++li)
+    for (int bi = 0; bi < kBlocks[li]; ++bi) block_names.push_back("layer" + std::to_string(li + 1) + "." + std::to_string(bi));
+  bool tapped = false;
+  // One Bottleneck on nn frames: x -> y through the branch temporaries t1, t2 (and idb for an un-fused downsample).
+  auto run_block = [&](size_t k, int nn, float *x, float *y, int hh, int ww) -> int {
     const Block &blk = e->blocks[k];
-    const std::string name = "layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+    const std::string &name = block_names[k];
     const ConvLayer &c1 = e->convs[blk.conv1], &c2 = e->convs[blk.conv2], &c3 = e->convs[blk.conv3];
-    const int ho = (h + 2 - 3) / blk.stride + 1, wo = (w + 2 - 3) / blk.stride + 1;
-    const float *identity = cur;
+    const int ho = (hh + 2 - 3) / blk.stride + 1, wo = (ww + 2 - 3) / blk.stride + 1;
+    const float *identity = x;
     const bool fused = blk.down >= 0 && blk.d_wf != nullptr;
     if (blk.down >= 0 && !fused) {
-      tsm::ConvParams pd = make_params(e->convs[blk.down], cur, nullptr, idb, n, h, w, false, 0, 1, prec);
+      tsm::ConvParams pd = make_params(e->convs[blk.down], x, nullptr, idb, nn, hh, ww, false, 0, 1, prec);
       int rcd = conv(blk.down, pd, 1, false);
       if (rcd) return rcd;
       identity = idb;
@@ -435,18 +439,18 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       e->cur_timing->push_back(nullptr);
       e->cur_timing->push_back(nullptr);
     }
-    tsm::ConvParams p1 = make_params(c1, cur, nullptr, t1, n, h, w, true, shiftT, cfg.shift_div, prec);
+    tsm::ConvParams p1 = make_params(c1, x, nullptr, t1, nn, hh, ww, true, shiftT, cfg.shift_div, prec);
     int rc1 = conv(blk.conv1, p1, 1, false);
     if (rc1) return rc1;
-    if (want(name + ".conv1")) return hit(t1, n, h, w, c1.cout);
-    tsm::ConvParams p2 = make_params(c2, t1, nullptr, t2, n, h, w, true, 0, 1, prec);
+    if (want(name + ".conv1")) { tapped = true; return hit(t1, nn, hh, ww, c1.cout); }
+    tsm::ConvParams p2 = make_params(c2, t1, nullptr, t2, nn, hh, ww, true, 0, 1, prec);
     // conv2 + conv3 + residual in one kernel where the block is eligible: bit 0x400 of conv2's tile code (set by the
     // tuning pass when the fused launch beat the two separate ones), or forced / forbidden through TSM_FUSE_CONV23
     tsm::Fused23Params pf{};
     const bool can_fuse = blk.d_w3f != nullptr && e->fuse23 != 0 && !want(name + ".conv2");
     if (can_fuse) {
-      pf.x = t1; pf.w2 = c2.d_w; pf.bias2 = c2.d_b; pf.w3f = blk.d_w3f; pf.bias3 = c3.d_b; pf.res = identity; pf.y = out;
-      pf.N = n; pf.H = h; pf.W = w; pf.M = n * h * w; pf.kseg_len = c2.kseg;
+      pf.x = t1; pf.w2 = c2.d_w; pf.bias2 = c2.d_b; pf.w3f = blk.d_w3f; pf.bias3 = c3.d_b; pf.res = identity; pf.y = y;
+      pf.N = nn; pf.H = hh; pf.W = ww; pf.M = nn * hh * ww; pf.kseg_len = c2.kseg;
     }
     if (can_fuse && !tuning && (e->fuse23 == 1 || (tiles && ((*tiles)[blk.conv2] & 0x400)))) {
       TSM_LAUNCH_K(e, s, true, tsm::launch_conv23_fused(pf, blk.cmid, s));
@@ -454,21 +458,18 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
         e->cur_timing->push_back(nullptr);
         e->cur_timing->push_back(nullptr);
       }
-      if (want(name)) return hit(out, n, ho, wo, c3.cout);
-      std::swap(cur, out);
-      h = ho; w = wo;
-      if (++bi == kBlocks[li]) { bi = 0; ++li; }
-      continue;
+      if (want(name)) { tapped = true; return hit(y, nn, ho, wo, c3.cout); }
+      return TSM_OK;
     }
     int rc2 = conv(blk.conv2, p2, 3, true);
     if (rc2) return rc2;
     const float ms2 = e->last_tune_ms;
-    if (want(name + ".conv2")) return hit(t2, n, ho, wo, c2.cout);
-    tsm::ConvParams p3 = make_params(c3, t2, fused ? nullptr : identity, out, n, ho, wo, true, 0, 1, prec);
+    if (want(name + ".conv2")) { tapped = true; return hit(t2, nn, ho, wo, c2.cout); }
+    tsm::ConvParams p3 = make_params(c3, t2, fused ? nullptr : identity, y, nn, ho, wo, true, 0, 1, prec);
     if (fused) {
       const ConvLayer &cd = e->convs[blk.down];
       p3.w = blk.d_wf; p3.bias = blk.d_bf; p3.Kp = blk.kpf; p3.K1 = c3.kp; p3.kseg_len = blk.ksegf;
-      p3.x2 = cur; p3.C2 = cd.cp; p3.Hi2 = h; p3.Wi2 = w; p3.stride2 = blk.stride;
+      p3.x2 = x; p3.C2 = cd.cp; p3.Hi2 = hh; p3.Wi2 = ww; p3.stride2 = blk.stride;
     }
     int rc3 = conv(blk.conv3, p3, 1, false);
     if (rc3) return rc3;
@@ -483,10 +484,15 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       }
       if ((ms[1] < ms[2] ? ms[1] : ms[2]) < ms2 + e->last_tune_ms) (*tiles)[blk.conv2] |= 0x400;
     }
-    if (want(name)) return hit(out, n, ho, wo, c3.cout);
+    if (want(name)) { tapped = true; return hit(y, nn, ho, wo, c3.cout); }
+    return TSM_OK;
+  };
+  for (size_t k = 0; k < e->blocks.size(); ++k) {
+    int rc = run_block(k, n, cur, out, h, w);
+    if (rc || tapped) return rc;
     std::swap(cur, out);
-    h = ho; w = wo;
-    if (++bi == kBlocks[li]) { bi = 0; ++li; }
+    h = (h + 2 - 3) / e->blocks[k].stride + 1;
+    w = (w + 2 - 3) / e->blocks[k].stride + 1;
   }
   if (stage) return fail(e, TSM_ERR_INVALID_ARG, std::string("unknown stage: ") + stage);
   TSM_LAUNCH(e, s, tsm::launch_head(cur, e->d_fcw, e->d_fcb, e->d_pooled, d_logits, n_clips, T, h * w, 2048,
