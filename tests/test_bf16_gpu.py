@@ -91,8 +91,8 @@ def test_tile_choice_is_bitwise_neutral_in_bf16_modes(hip_lib, sd0, monkeypatch,
                       ('64x64', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '64x64'}),
                       ('128x128', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '128x128'}),
                       ('128x128w8', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '128x128w8'}),
-                      # the 8-wave LDS-DMA kernel wherever it applies (bf16, Cout % 256 == 0, no residual): conv3 of
-                      # layer1.0-4.0 are excluded by their fused second source, conv2 / conv1 of layer3-4 run on it
+                      # the 8-wave LDS-DMA kernel wherever it applies (bf16, Cout % 256 == 0): every conv3 (residual
+                      # arm; K-concatenated downsample arm in the first block of a stage), conv2 / conv1 of layer3-4
                       ('256x256', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '256x256'})]:
         for k in ('TSM_AUTOTUNE', 'TSM_CONV_TILE'):
             monkeypatch.delenv(k, raising=False)
@@ -144,16 +144,20 @@ def test_fused_stem_maxpool_equals_separate_kernels_bitwise(hip_lib, sd0, monkey
     assert got['1'][0].shape == (16, (h // 2 + 1) // 2, (w // 2 + 1) // 2, 64)
 
 
-@pytest.mark.parametrize('n,hi,wi,cin,cout,k,stride,relu,shiftT', [
-    (8, 16, 16, 256, 256, 3, 1, True, 0),       # layer3 conv2 at the config-5 size: 2048 rows = 8 full tiles
-    (4, 16, 16, 256, 256, 3, 2, True, 0),       # stride 2 (layer3.0 / layer4.0 conv2): 256 rows
-    (3, 7, 9, 512, 512, 3, 1, False, 0),        # ragged: 189 rows in one tile, two n-tiles, K = 4608 (72 K-tiles)
-    (8, 14, 14, 1024, 256, 1, 1, True, 8),      # layer3 conv1 with the fused temporal shift, 1568 rows (ragged last tile)
-    (4, 8, 8, 2048, 512, 1, 1, True, 4),        # layer4 conv1, T = 4
-    (2, 20, 20, 64, 256, 1, 1, True, 0),        # a single K-tile (K = 64): prologue + dead stages only
-    (2, 12, 12, 64, 256, 3, 1, True, 0),        # K = 576 = 9 K-tiles (odd count)
+@pytest.mark.parametrize('n,hi,wi,cin,cout,k,stride,relu,shiftT,use_res', [
+    (8, 16, 16, 256, 256, 3, 1, True, 0, False),   # layer3 conv2 at the config-5 size: 2048 rows = 8 full tiles
+    (4, 16, 16, 256, 256, 3, 2, True, 0, False),   # stride 2 (layer3.0 / layer4.0 conv2): 256 rows
+    (3, 7, 9, 512, 512, 3, 1, False, 0, False),    # ragged: 189 rows in one tile, two n-tiles, K = 4608 (72 K-tiles)
+    (8, 14, 14, 1024, 256, 1, 1, True, 8, False),  # layer3 conv1 with the fused temporal shift, 1568 rows (ragged last tile)
+    (4, 8, 8, 2048, 512, 1, 1, True, 4, False),    # layer4 conv1, T = 4
+    (2, 20, 20, 64, 256, 1, 1, True, 0, False),    # a single K-tile (K = 64): prologue + dead stages only
+    (2, 12, 12, 64, 256, 3, 1, True, 0, False),    # K = 576 = 9 K-tiles (odd count)
+    (4, 16, 16, 256, 1024, 1, 1, True, 0, True),   # layer3 conv3 + residual: four n-tiles
+    (3, 9, 7, 128, 512, 1, 1, True, 0, True),      # layer2 conv3 + residual, ragged (189 rows), K = 128
+    (2, 8, 8, 512, 2048, 1, 1, False, 0, True),    # layer4 conv3 + residual, no ReLU
 ])
-def test_lds_dma_256_tile_equals_the_128_tiles_bitwise(hip_lib, monkeypatch, n, hi, wi, cin, cout, k, stride, relu, shiftT):
+def test_lds_dma_256_tile_equals_the_128_tiles_bitwise(hip_lib, monkeypatch, n, hi, wi, cin, cout, k, stride, relu, shiftT,
+                                                       use_res):
     """conv_bf16_256_kernel (256 x 256 tile, 8 waves, LDS-DMA staging, counted vmcnt) against conv_igemm's bf16 tiles
     through the per-op entry point: same k order per output -> same bits; and both against the fp32 oracle at the
     bf16 mode's tolerance."""
@@ -162,12 +166,16 @@ def test_lds_dma_256_tile_equals_the_128_tiles_bitwise(hip_lib, monkeypatch, n, 
     x = torch.randn(n, cin, hi, wi, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
     bn = _bn(cout, g)
+    pad = k // 2
+    ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
+    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
     outs = {}
     for tile in ('256x256', '128x128', '64x64'):
         monkeypatch.setenv('TSM_CONV_TILE', tile)
         outs[tile] = conv_bn_act_nhwc(_nhwc(x).cuda(), w.cuda(), *[b.cuda() for b in bn], stride=stride, relu=relu,
+                                      residual=None if res is None else _nhwc(res).cuda(),
                                       shift_segments=shiftT, fold_div=8, dtype='bf16').cpu()
     assert torch.equal(outs['256x256'], outs['128x128']) and torch.equal(outs['256x256'], outs['64x64'])
     xin = tsm_oracle.temporal_shift(x, shiftT, 8) if shiftT else x
-    want = tsm_oracle.conv_bn_act(xin, w, bn, stride, k // 2, relu, None)
+    want = tsm_oracle.conv_bn_act(xin, w, bn, stride, k // 2, relu, res)
     assert_close(_nchw(outs['256x256']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='256x256 bf16')

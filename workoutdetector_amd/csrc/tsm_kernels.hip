@@ -812,7 +812,8 @@ bool conv_tile_valid(const ConvParams &p, int tile) {
     case kTile32x32: return p.Cout % 32 == 0 && p.prec == kPrecF32;  // single-wave tiles: fp32 only
     case kTile128x128w8: return p.Cout % 128 == 0;
     case kTile256x256:   // (ks is checked at launch: the stem has C == 4 and never qualifies)
-      return p.prec == kPrecBf16 && p.Cout % 256 == 0 && p.C % 64 == 0 && !p.res && !p.x2;
+      return p.prec == kPrecBf16 && p.Cout % 256 == 0 && p.C % 64 == 0 && !(p.res && p.x2) &&
+             (!p.x2 || (p.K1 % 64 == 0 && p.C2 % 64 == 0));
     default: return false;
   }
 }
@@ -834,7 +835,7 @@ static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
     conv_tile_dims(p.tile, &bm, &bn);
   }
   if (p.tile == kTile256x256) {
-    if constexpr (KS != 7 && !RES) return launch_conv_bf16_256(p, KS, s);
+    if constexpr (KS != 7) return launch_conv_bf16_256(p, KS, s);
     else return hipErrorInvalidValue;
   }
   if (p.kseg_len > 0 && !(bm == 32 && bn == 32)) {  // segmented accumulation exists on 64x64 / 32x32 tiles only
@@ -905,12 +906,15 @@ hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
 // Per output the products enter the accumulator in conv_igemm's order (k16 groups ascending), so results are
 // bit-identical to the other bf16 tiles.  Epilogue: accumulators -> wave-private LDS slab (no workgroup barrier)
 // -> + bias, ReLU, bf16, 16-byte stores of whole 128-byte row segments.
-// Needs Cout % 256 == 0, C % 64 == 0, no residual / second source; the tuner picks it where it wins (long K, at least
-// one tile per CU: conv2 and conv1 of layer3-4 at the config-5 size).
+// Needs Cout % 256 == 0 and C % 64 == 0.  Template arms: KS = 3; KS = 1 with the fused temporal shift (conv1), with a
+// residual (conv3) or with the K-concatenated second source (conv3 + downsample).  The tuner picks it where it wins
+// (at least about one tile per CU; long K helps: conv2 and conv1 of layer3-4 at the config-5 size).
 // ---------------------------------------------------------------------------------------------
-template <int KS, bool SHIFT>
+template <int KS, bool SHIFT, bool RES = false, bool DUAL = false>
 __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams p) {
   static_assert(KS == 1 || KS == 3, "1x1 (optionally temporally shifted) and 3x3");
+  static_assert(!(RES || DUAL) || (KS == 1 && !SHIFT), "residual / K-concatenated second source: plain 1x1 convs (conv3)");
+  static_assert(!(RES && DUAL), "the fused conv3 + downsample GEMM has no residual");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 buffers x 64 KB; epilogue: 8 x 8704 B
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -934,9 +938,17 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams 
   const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char *>(reinterpret_cast<const char *>(p.w) + (size_t)n0 * p.Kp * 2), 0, 256 * p.Kp * 2, 0x00020000);
 
+  // second A source (DUAL: conv3 + downsample as one GEMM, K = [conv3 input channels | block input channels])
+  const int frame_bytes2 = DUAL ? p.Hi2 * p.Wi2 * p.C2 * 2 : 0;
+  const size_t a2_bytes = DUAL ? ((size_t)p.N - n_first) * (size_t)frame_bytes2 : 0;
+  const __amdgpu_buffer_rsrc_t rsrcA2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(reinterpret_cast<const char *>(DUAL ? p.x2 : p.x) + (size_t)n_first * frame_bytes2), 0,
+      (int)(a2_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : a2_bytes), 0x00020000);
+  const int nt1 = DUAL ? p.K1 / 64 : 0;                   // K-tiles of the first source
+
   // ---- loader state: this lane fills LDS slot (row, lane & 3) of rows piece * 16 + (lane >> 2), piece = 2 * wave + q
   const int chunk = (lane & 3) ^ ((lane >> 4) & 3);      // global 16-B chunk held by that slot (swizzle on the source)
-  unsigned a_off[2], a_offp[SHIFT ? 2 : 1], a_offm[SHIFT ? 2 : 1], a_mask[KS == 3 ? 2 : 1], b_off[2];
+  unsigned a_off[2], a_offp[SHIFT ? 2 : 1], a_offm[SHIFT ? 2 : 1], a_mask[KS == 3 ? 2 : 1], b_off[2], a_off2[DUAL ? 2 : 1];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int row = (2 * wave + q) * 16 + (lane >> 2);
@@ -962,6 +974,9 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams 
       a_offp[q] = (ok && t < p.T - 1) ? (unsigned)(base + frame_bytes) : kInvalid;
       a_offm[q] = (ok && t > 0) ? (unsigned)(base - frame_bytes) : kInvalid;
     }
+    if (DUAL)
+      a_off2[q] = ok ? (unsigned)((n - n_first) * frame_bytes2 + (oy * p.stride2 * p.Wi2 + ox * p.stride2) * p.C2 * 2 + chunk * 16)
+                     : kInvalid;
     b_off[q] = (unsigned)(row * p.Kp * 2 + chunk * 16);
   }
   const int nt = p.Kp / 64;                               // K-tiles
@@ -984,11 +999,16 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams 
         mm_ = (0u - (unsigned)(c < 2 * p.fold)) & ~mp;
         m0_ = ~(mp | mm_);
       }
+      const bool second = DUAL && kt >= nt1;               // wave-uniform: which source this K-tile comes from
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         unsigned off = a_off[q];
         if (SHIFT) off = (a_offp[q] & mp) | (a_offm[q] & mm_) | (a_off[q] & m0_);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(dst + q * 1024), 16, (int)(off | dead), (int)kbytes, 0, 0);
+        if (DUAL && second)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, (lds_void *)(dst + q * 1024), 16, (int)(a_off2[q] | dead),
+                                                   (int)(kbytes - (unsigned)nt1 * 128u), 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(dst + q * 1024), 16, (int)(off | dead), (int)kbytes, 0, 0);
       }
     } else {
       const int tap = (kt * 64) >> (p.logC4 + 2);         // C >= 64: a K-tile never straddles a tap
@@ -1079,8 +1099,23 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams 
   const int c8 = lane & 7, r8l = lane >> 3;
   const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 64 + c8 * 8);
   const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 64 + c8 * 8 + 4);
+  // residual (RES): the 8 channels of this lane's row segment, fetched one slab ahead of their use
+  const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>(reinterpret_cast<const char *>(RES ? p.res : p.y) + (size_t)m0 * p.Cout * 2), 0,
+      (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
+  u32x4 rres[2][RES ? 4 : 1];
+  auto load_res = [&](int i, int set) {
+    if constexpr (RES) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        rres[set][k] = __builtin_amdgcn_raw_buffer_load_b128(
+            rsrcR, ((wm * 128 + i * 32 + r8l + 8 * k) * p.Cout + n0 + wn * 64 + c8 * 8) * 2, 0, 0);
+    }
+  };
+  load_res(0, 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    if (i + 1 < 4) load_res(i + 1, (i + 1) & 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1091,11 +1126,15 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams 
       const int rr = r8l + 8 * k;
       const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cs + rr * 68 + c8 * 8);
       const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cs + rr * 68 + c8 * 8 + 4);
+      float v[8] = {c0[0] + bias0[0], c0[1] + bias0[1], c0[2] + bias0[2], c0[3] + bias0[3],
+                    c1[0] + bias1[0], c1[1] + bias1[1], c1[2] + bias1[2], c1[3] + bias1[3]};
+      if constexpr (RES) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += split_elem(rres[i & 1][k], e);
+      }
       u32x4 o;
-      o[0] = pack_bf16(fmaxf(c0[0] + bias0[0], floor_), fmaxf(c0[1] + bias0[1], floor_));
-      o[1] = pack_bf16(fmaxf(c0[2] + bias0[2], floor_), fmaxf(c0[3] + bias0[3], floor_));
-      o[2] = pack_bf16(fmaxf(c1[0] + bias1[0], floor_), fmaxf(c1[1] + bias1[1], floor_));
-      o[3] = pack_bf16(fmaxf(c1[2] + bias1[2], floor_), fmaxf(c1[3] + bias1[3], floor_));
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) o[w2] = pack_bf16(fmaxf(v[2 * w2], floor_), fmaxf(v[2 * w2 + 1], floor_));
       const int row = wm * 128 + i * 32 + rr;
       __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (row * p.Cout + n0 + wn * 64 + c8 * 8) * 2, 0, 0);
     }
@@ -1104,8 +1143,12 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams 
 }
 
 bool conv_bf16_256_valid(const ConvParams &p, int ks) {
-  return p.prec == kPrecBf16 && (ks == 1 || ks == 3) && p.Cout % 256 == 0 && p.C % 64 == 0 && p.Kp % 64 == 0 && !p.res &&
-         !p.x2 && p.kseg_len == 0 && (ks == 1 || p.T == 0);
+  if (p.prec != kPrecBf16 || (ks != 1 && ks != 3) || p.Cout % 256 != 0 || p.C % 64 != 0 || p.Kp % 64 != 0 || p.kseg_len != 0)
+    return false;
+  if (ks == 3) return !p.res && !p.x2 && p.T == 0;
+  if (p.T > 0) return !p.res && !p.x2;                    // shifted conv1
+  if (p.x2) return !p.res && p.K1 % 64 == 0 && p.C2 % 64 == 0;
+  return true;
 }
 
 static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s) {
@@ -1119,10 +1162,14 @@ static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     attr_set = true;
   }
   if (ks == 3) hipLaunchKernelGGL((conv_bf16_256_kernel<3, false>), grid, block, kLdsBytes, s, p);
   else if (p.T > 0) hipLaunchKernelGGL((conv_bf16_256_kernel<1, true>), grid, block, kLdsBytes, s, p);
+  else if (p.res) hipLaunchKernelGGL((conv_bf16_256_kernel<1, false, true, false>), grid, block, kLdsBytes, s, p);
+  else if (p.x2) hipLaunchKernelGGL((conv_bf16_256_kernel<1, false, false, true>), grid, block, kLdsBytes, s, p);
   else hipLaunchKernelGGL((conv_bf16_256_kernel<1, false>), grid, block, kLdsBytes, s, p);
   return hipGetLastError();
 }
