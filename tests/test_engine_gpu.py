@@ -292,10 +292,11 @@ def test_tune_cache_file_round_trip(hip_lib, sd0, tmp_path, monkeypatch):
     assert len(path.read_text().splitlines()) == 2
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16x3'])
 @pytest.mark.parametrize('h,w,b', [(224, 224, 2), (96, 96, 3), (90, 70, 1)])
-def test_fused_conv2_conv3_equals_the_separate_kernels_bitwise(hip_lib, sd0, monkeypatch, h, w, b):
+def test_fused_conv2_conv3_equals_the_separate_kernels_bitwise(hip_lib, sd0, monkeypatch, h, w, b, dtype):
     """conv23_fused (Bottleneck.conv2 + bn2 + ReLU + conv3 + bn3 + residual + ReLU in one kernel, the mid tensor kept in
-    LDS; layer1.1-2 and layer2.1-3 of an fp32 engine) against the two separate launches: same k order, same segment
+    LDS; layer1.1-2 and layer2.1-3 of an fp32 or split-bf16 engine) against the two separate launches: same k order, same segment
     sums, same epilogue arithmetic -> same bits, on block-output taps and logits, including ragged last tiles
     (90x70: 414 / 108 pixels per frame) and the segmented-K layer2 convs."""
     from workoutdetector_amd.engine import TsmEngine
@@ -303,7 +304,7 @@ def test_fused_conv2_conv3_equals_the_separate_kernels_bitwise(hip_lib, sd0, mon
     got = {}
     for flag in ('1', '0'):
         monkeypatch.setenv('TSM_FUSE_CONV23', flag)
-        eng = TsmEngine(height=h, width=w, max_clips=b, state_dict=sd0)
+        eng = TsmEngine(height=h, width=w, max_clips=b, state_dict=sd0, dtype=dtype)
         got[flag] = [eng.run(None, {'input': x})[0]] + [eng.forward_tap(x, s) for s in ('layer1.1', 'layer1.2', 'layer2.3')]
         if flag == '1':
             tiles = eng.conv_tiles(b)
@@ -312,9 +313,9 @@ def test_fused_conv2_conv3_equals_the_separate_kernels_bitwise(hip_lib, sd0, mon
         assert np.array_equal(a, c)
     monkeypatch.delenv('TSM_FUSE_CONV23')
     # left to the tuner, the choice is timing-based and bit-neutral
-    eng = TsmEngine(height=h, width=w, max_clips=b, state_dict=sd0)
+    eng = TsmEngine(height=h, width=w, max_clips=b, state_dict=sd0, dtype=dtype)
     assert np.array_equal(eng.run(None, {'input': x})[0], got['0'][0])
     picked = sorted(k for k, v in eng.conv_tiles(b).items() if v.endswith('+conv3'))
-    print(f'\n[{h}x{w} b{b}: fused conv2+conv3 picked by the tuner for] {picked}')
+    print(f'\n[{dtype} {h}x{w} b{b}: fused conv2+conv3 picked by the tuner for] {picked}')
     assert set(picked) <= {'layer1.1.conv2', 'layer1.2.conv2', 'layer2.1.conv2', 'layer2.2.conv2', 'layer2.3.conv2'}
     eng.close()

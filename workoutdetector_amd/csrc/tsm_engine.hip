@@ -53,7 +53,7 @@ struct Block {
   float *d_wf = nullptr, *d_bf = nullptr;
   int kpf = 0;
   int ksegf = 0;  // segment length of the fused GEMM
-  // conv2 + conv3 (+ residual) as ONE kernel (tsm::launch_conv23_fused): fp32 blocks without a downsample branch whose
+  // conv2 + conv3 (+ residual) as ONE kernel (tsm::launch_conv23_fused): fp32 / split-bf16 blocks without a downsample branch whose
   // mid tensor has 64 / 128 channels (layer1.1-2, layer2.1-3); d_w3f = conv3's folded weights in fragment order
   float *d_w3f = nullptr;
   int cmid = 0;
@@ -453,7 +453,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       pf.N = nn; pf.H = hh; pf.W = ww; pf.M = nn * hh * ww; pf.kseg_len = c2.kseg;
     }
     if (can_fuse && !tuning && (e->fuse23 == 1 || (tiles && ((*tiles)[blk.conv2] & 0x400)))) {
-      TSM_LAUNCH_K(e, s, true, tsm::launch_conv23_fused(pf, blk.cmid, s));
+      TSM_LAUNCH_K(e, s, true, tsm::launch_conv23_fused(pf, blk.cmid, prec, s));
       if (e->cur_timing) {  // keep conv3's launch slot: reported as "not recorded"
         e->cur_timing->push_back(nullptr);
         e->cur_timing->push_back(nullptr);
@@ -477,7 +477,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       float ms[3];
       for (int rep = 0; rep < 3; ++rep) {
         TSM_HIP(e, hipEventRecord(e->ev0, s));
-        TSM_HIP(e, tsm::launch_conv23_fused(pf, blk.cmid, s));
+        TSM_HIP(e, tsm::launch_conv23_fused(pf, blk.cmid, prec, s));
         TSM_HIP(e, hipEventRecord(e->ev1, s));
         TSM_HIP(e, hipEventSynchronize(e->ev1));
         TSM_HIP(e, hipEventElapsedTime(&ms[rep], e->ev0, e->ev1));
@@ -688,12 +688,13 @@ int tsm_finalize(tsm_engine *e) {
     TSM_HIP(e, hipMemcpy(blk.d_bf, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   // Blocks without a downsample branch whose mid tensor is 64 / 128 channels wide: conv3's weights once more, in the
-  // fragment order of the fused conv2 + conv3 kernel (fp32 engines).
+  // fragment order of the fused conv2 + conv3 kernel (fp32 and split-bf16 engines).
   for (Block &blk : e->blocks) {
     const ConvLayer &c2 = e->convs[blk.conv2], &c3 = e->convs[blk.conv3];
-    if (e->prec != tsm::kPrecF32 || blk.down >= 0 || blk.stride != 1 || (c2.cout != 64 && c2.cout != 128)) continue;
+    if (e->prec == tsm::kPrecBf16 || blk.down >= 0 || blk.stride != 1 || (c2.cout != 64 && c2.cout != 128)) continue;
     std::vector<float> w3f;
-    pack_w3_fragments(host_wp[blk.conv3].data(), c2.cout, &w3f);
+    if (e->prec == tsm::kPrecBf16x3) pack_w3_fragments_split(host_wp[blk.conv3].data(), c2.cout, &w3f);
+    else pack_w3_fragments(host_wp[blk.conv3].data(), c2.cout, &w3f);
     int rcw = dev_alloc(e, &blk.d_w3f, w3f.size());
     if (rcw) return rcw;
     TSM_HIP(e, hipMemcpy(blk.d_w3f, w3f.data(), w3f.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -124,6 +124,29 @@ inline void pack_w3_fragments(const float *w3p, int cmid, std::vector<float> *ou
           }
 }
 
+// The same for a split-bf16 engine: per output chunk j, wave wn and k16 group kq the kernel loads TWO 16-byte elements
+// per lane, the hi and the lo halves of the 8 channels k = 16 kq + 8 (lane >> 5) + 0..7 of row n:
+//   element (((j * wgn + wn) * (2 * nkq) + 2 * kq + part) * 64 + lane), part 0 = hi x8, 1 = lo x8  (bf16 pairs per float slot)
+// with hi = bf16(w), lo = bf16(w - hi) exactly as to_split() stores the conv3 weights of the un-fused path.
+inline void pack_w3_fragments_split(const float *w3p, int cmid, std::vector<float> *out) {
+  const int wgn = cmid / 32, nkq = cmid / 16;
+  out->assign((size_t)4 * cmid * cmid, 0.f);
+  uint16_t *o = reinterpret_cast<uint16_t *>(out->data());
+  for (int j = 0; j < 4; ++j)
+    for (int wn = 0; wn < wgn; ++wn)
+      for (int kq = 0; kq < nkq; ++kq)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int n = j * cmid + wn * 32 + (lane & 31), k0 = 16 * kq + 8 * (lane >> 5);
+          const size_t base = ((((size_t)j * wgn + wn) * (2 * nkq) + 2 * kq) * 64 + lane) * 8;   // in bf16 units
+          for (int e = 0; e < 8; ++e) {
+            const float x = w3p[(size_t)n * cmid + k0 + e];
+            const uint16_t hi = f2bf(x);
+            o[base + e] = hi;
+            o[base + 64 * 8 + e] = f2bf(x - bf2f(hi));
+          }
+        }
+}
+
 // One line of a TSM_TUNE_CACHE file: "<signature>|<bucket>|c0,c1,...".  Succeeds only when the line starts with
 // `want`, holds exactly codes->size() integers and each is a ConvTile below `num_tiles`, optionally | 0x100 (split-K) | 0x400 (block runs conv2 + conv3 fused).
 // Anything else (foreign keys, truncated lines, garbage, overlong numbers) leaves *codes untouched.

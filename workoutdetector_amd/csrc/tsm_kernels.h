@@ -56,14 +56,14 @@ bool conv_tile_valid(const ConvParams &p, int tile);
 
 // ks in {1, 3, 7}.  Returns hipSuccess or the launch error.
 hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s);
-// Bottleneck.conv2 (3x3, stride 1, pad 1) + bn2 + ReLU + conv3 (1x1) + bn3 + residual + ReLU as ONE launch (fp32),
+// Bottleneck.conv2 (3x3, stride 1, pad 1) + bn2 + ReLU + conv3 (1x1) + bn3 + residual + ReLU as ONE launch (fp32 or split-bf16),
 // for CMID = 64 / 128 (layer1 / layer2 blocks without a downsample branch).  Bit-identical to launch_conv(conv2)
 // followed by launch_conv(conv3 with residual).
 struct Fused23Params {
   const float *x;      // conv2 input [N, H, W, CMID]
   const float *w2;     // [CMID][9 * CMID]  conv2 weights, K = (ky, kx, c), bn2 scale folded in
   const float *bias2;  // [CMID]
-  const float *w3f;    // conv3 weights (bn3 scale folded in) in MFMA-fragment order, tsm_host::pack_w3_fragments
+  const float *w3f;    // conv3 weights (bn3 scale folded in) in MFMA-fragment order, tsm_host::pack_w3_fragments[_split]
   const float *bias3;  // [4 * CMID]
   const float *res;    // [M, 4 * CMID]  the block input (identity branch)
   float *y;            // [M, 4 * CMID]
@@ -71,7 +71,7 @@ struct Fused23Params {
   int M;               // N * H * W
   int kseg_len;        // conv2's K-segment length (ConvParams::kseg_len of that layer; 0 = unsegmented)
 };
-hipError_t launch_conv23_fused(const Fused23Params &p, int cmid, hipStream_t s);
+hipError_t launch_conv23_fused(const Fused23Params &p, int cmid, int prec, hipStream_t s);
 
 // Stem (7x7 s2 p3, 3 -> 64) of the bf16 formats as a direct convolution from an LDS-resident pixel-pair patch; x is the
 // packed-pair input [n][hi][ceil(wi/2)][8], w the engine's packed stem weights [64][kp], y NHWC, all in `prec`'s format
