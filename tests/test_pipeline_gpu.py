@@ -190,3 +190,20 @@ def test_two_rank_dataset_inference_with_real_engines(hip_lib, tmp_path, golden_
     assert sorted(os.listdir(single)) == sorted(os.listdir(sharded)) and len(os.listdir(single)) == 3
     for f in os.listdir(single):
         assert json.load(open(os.path.join(single, f))) == json.load(open(os.path.join(sharded, f))), f
+
+
+def test_oversized_videos_are_staged_in_pieces(probe_engine, monkeypatch):
+    """A video whose even frames exceed inference_count.MAX_STAGE_BYTES (1 GiB by default: long 1080p videos) is not
+    pinned / uploaded whole: the clip range is walked in pieces, each re-staging the frames its windows overlap.
+    Same logits bit for bit, including the zero-padded tail clip and a piece boundary inside the video."""
+    from workoutdetector_amd import inference_count as ic
+    from workoutdetector_amd.transform import build_test_transform
+    eng, _ = probe_engine
+    vid = torch.from_numpy(synthetic_video(77, 333, 90, 52, period=24))      # 42 clips, 167 even frames of 14 040 B
+    tf = build_test_transform(False)
+    whole = ic.video_clip_logits(eng, vid, tf, batch_clips=16)
+    monkeypatch.setattr(ic, 'MAX_STAGE_BYTES', 40 * 90 * 52 * 3)             # room for 40 even frames -> 8 clips per piece
+    pieces = ic.video_clip_logits(eng, vid, tf, batch_clips=16)
+    assert tuple(whole.shape) == (42, 12) and torch.equal(whole, pieces)
+    part = ic.video_clip_logits(eng, vid, tf, clip_range=(5, 31), batch_clips=16)   # a rank's block of a sharded video
+    assert torch.equal(part, whole[5:31])

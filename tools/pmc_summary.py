@@ -22,7 +22,7 @@ def main(cc_path, kt_path):
     lo, hi = packs[-2], packs[-1]
     cols = None
     for d in ids:
-        if not (lo <= d < hi) or 'conv_' not in names[d]:
+        if not (lo <= d < hi) or 'conv' not in names[d]:
             continue
         c = per[d]
         if cols is None:
@@ -31,6 +31,8 @@ def main(cc_path, kt_path):
                   'mfma_util'.rjust(9), 'clkGHz'.rjust(7))
         us = dur.get(d, 0.0)
         kn = names[d].split('<')[1].split('>')[0].replace(' ', '') if '<' in names[d] else names[d][:30]
+        if 'conv_igemm' not in names[d]:      # conv23_fused_kernel<..>, conv_bf16_256_kernel<..>: keep the kernel's name
+            kn = names[d].split('tsm::')[1].split('(')[0].replace(' ', '').replace('_kernel', '')
         # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs? normalise by BUSY_CU_CYCLES*... report ratio to GUI_ACTIVE
         gui = c.get('GRBM_GUI_ACTIVE', 0.0)
         clk = gui / 8.0 / (us * 1e3) if us else 0.0   # sum over 8 XCDs; cycles per ns

@@ -36,6 +36,7 @@ import contextlib
 import json
 import os
 import os.path as osp
+import threading
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
@@ -53,6 +54,10 @@ NUM_SEGMENTS = 8
 CLIP_SPAN = 16
 CLIP_STRIDE = 2
 CLIP_STEP = 8
+# Upper bound on the uint8 frames of one video staged (page-locked + on the device) at a time.  A long 1080p video
+# holds several GB of even frames; beyond this bound the clip range is processed in pieces (each piece re-stages the
+# 8-frame overlap it needs), so pinned host memory stays <= 3 pool slots x 1.25 x this and device memory proportional.
+MAX_STAGE_BYTES = 1 << 30
 
 
 # ---- video sources -------------------------------------------------------------------------------------
@@ -134,10 +139,12 @@ class _PinnedPool:
         self.bufs: List[Optional[torch.Tensor]] = [None] * slots
         self.busy: List[Optional[object]] = [None] * slots      # event of the last copy out of the slot
         self.next = 0
+        self.lock = threading.Lock()        # the prefetch worker thread and a StreamBatcher may share the pool
 
     def take(self, nbytes: int) -> Tuple[torch.Tensor, int]:
-        i = self.next
-        self.next = (i + 1) % len(self.bufs)
+        with self.lock:
+            i = self.next
+            self.next = (i + 1) % len(self.bufs)
         if self.busy[i] is not None:
             self.busy[i].synchronize()
             self.busy[i] = None
@@ -167,6 +174,10 @@ def stage_video(model, video_thwc_u8: torch.Tensor, clip_range: Optional[Tuple[i
     dev = _engine_device(model)
     if dev is None or not hasattr(model, 'packed_layout'):
         return StagedVideo(total, lo, hi, f_lo, hw, even, False)
+    if int(even.numel()) > MAX_STAGE_BYTES:
+        # too large to pin / upload in one piece: hand the (strided, un-copied) host view on; staged_clip_logits
+        # walks the clip range in pieces that fit
+        return StagedVideo(total, lo, hi, f_lo, hw, even, False)
     shape = (even.shape[0] + 1,) + tuple(even.shape[1:])
     flat, slot = _pinned_pool.take(int(np.prod(shape)))
     pinned = flat.view(shape)
@@ -188,6 +199,29 @@ def staged_clip_logits(model, st: StagedVideo, transform: TestTransform, batch_c
         return torch.empty((0, getattr(model, 'num_class', 0)), dtype=torch.float32)
     starts = clip_starts(st.total)
     dev = _engine_device(model)
+    if (not st.on_device and dev is not None and hasattr(model, 'packed_layout') and isinstance(transform, TestTransform)
+            and int(st.frames.numel()) > MAX_STAGE_BYTES):
+        # oversized video: pieces of consecutive clips whose even frames fit the staging bound, each staged on its own
+        per_frame = max(1, int(st.frames[0].numel()))
+        clips_per_piece = max(1, (MAX_STAGE_BYTES // per_frame - CLIP_SPAN // CLIP_STRIDE) // (CLIP_STEP // CLIP_STRIDE))
+        parts = []
+        for a in range(st.lo, st.hi, clips_per_piece):
+            b = min(a + clips_per_piece, st.hi)
+            f_a = starts[a] // CLIP_STRIDE
+            f_b = min((starts[b - 1] + CLIP_SPAN) // CLIP_STRIDE, (st.total + 1) // CLIP_STRIDE)
+            piece = st.frames[f_a - st.f_lo:f_b - st.f_lo]
+            shape = (piece.shape[0] + 1,) + tuple(piece.shape[1:])
+            flat, slot = _pinned_pool.take(int(np.prod(shape)))
+            pinned = flat.view(shape)
+            pinned[:-1].copy_(piece)
+            pinned[-1].zero_()
+            frames = pinned.to(dev, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record()
+            _pinned_pool.busy[slot] = ready
+            parts.append(staged_clip_logits(model, StagedVideo(st.total, a, b, f_a, st.hw, frames, True, ready, pinned),
+                                            transform, batch_clips))
+        return torch.cat(parts, dim=0)
     hip_transform = st.on_device and isinstance(transform, TestTransform)
     if hip_transform:
         # HIP path: uint8 frames (+ one zero frame for the padded tail) -> fused resize/crop/normalise
