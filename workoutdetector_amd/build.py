@@ -16,7 +16,9 @@ from typing import List
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), 'include')
-LIB_PATH = os.path.join(PKG_DIR, 'libtsm_hip.so')
+# (TSM_LIB_PATH / TSM_BUILD_DEFS: tooling hooks for A/B builds of one kernel variant against another, e.g.
+#  TSM_LIB_PATH=.../libtsm_hip_v1.so TSM_BUILD_DEFS='-DTSM_256_SCHED=1' python -m workoutdetector_amd.build --force)
+LIB_PATH = os.environ.get('TSM_LIB_PATH') or os.path.join(PKG_DIR, 'libtsm_hip.so')
 SOURCES = ['tsm_kernels.hip', 'tsm_engine.hip']
 ARCH = 'gfx950'
 
@@ -58,8 +60,8 @@ def is_stale() -> bool:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-I', INCLUDE, '-o', LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared'] + os.environ.get('TSM_BUILD_DEFS', '').split() + \
+          ['-I', INCLUDE, '-o', LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
