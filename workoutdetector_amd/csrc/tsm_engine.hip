@@ -361,15 +361,16 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
         if (tsm::conv_tile_valid(p, t)) cands.push_back(t);
     }
     for (int t : cands) {
-      float ms[3];
-      for (int rep = 0; rep < 3; ++rep) {
+      float ms[4];
+      for (int rep = 0; rep < 4; ++rep) {
         TSM_HIP(e, hipEventRecord(e->ev0, s));
         TSM_HIP(e, launch_code(p, ks, t));
         TSM_HIP(e, hipEventRecord(e->ev1, s));
         TSM_HIP(e, hipEventSynchronize(e->ev1));
         TSM_HIP(e, hipEventElapsedTime(&ms[rep], e->ev0, e->ev1));
       }
-      const float m = ms[1] < ms[2] ? ms[1] : ms[2];  // rep 0 warms the caches
+      float m = ms[1] < ms[2] ? ms[1] : ms[2];  // rep 0 warms the caches; best of the other three
+      m = ms[3] < m ? ms[3] : m;
       if (best == 0 || m < best_ms) {
         best = t;
         best_ms = m;
