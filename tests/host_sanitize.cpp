@@ -103,6 +103,46 @@ static void check_packing(unsigned seed) {
       for (size_t i = 3; i < wq.size(); i += 4) EXPECT(wq[i] == 0.f);   // channel 3 is padding everywhere
     }
   }
+  // conv3 weights in MFMA-fragment order (fused conv2 + conv3 kernel): a permutation of the packed matrix -- every
+  // weight lands exactly once, at the slot the kernel's lane / k-group arithmetic reads it from
+  for (int cmid : {64, 128}) {
+    std::vector<float> w3((size_t)4 * cmid * cmid), frag, fsplit;
+    for (size_t i = 0; i < w3.size(); ++i) w3[i] = (float)i + 0.25f;      // distinct, exactly representable
+    pack_w3_fragments(w3.data(), cmid, &frag);
+    EXPECT(frag.size() == w3.size());
+    std::vector<char> seen(w3.size(), 0);
+    const int wgn = cmid / 32, nkk = cmid / 8;
+    for (int j = 0; j < 4; ++j)
+      for (int wn = 0; wn < wgn; ++wn)
+        for (int kk = 0; kk < nkk; ++kk)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 4; ++e) {
+              const size_t src = (size_t)(j * cmid + wn * 32 + (lane & 31)) * cmid + 8 * kk + 4 * (lane >> 5) + e;
+              EXPECT(frag[((((size_t)j * wgn + wn) * nkk + kk) * 64 + lane) * 4 + e] == w3[src]);
+              EXPECT(!seen[src]);
+              seen[src] = 1;
+            }
+    for (char c : seen) EXPECT(c);
+    // split-bf16 form: hi / lo halves of the 8 channels of a k16 group, identical to what to_split() stores
+    for (float &x : w3) x = uni(rng);
+    pack_w3_fragments_split(w3.data(), cmid, &fsplit);
+    EXPECT(fsplit.size() == w3.size());
+    std::vector<float> ref = w3;
+    to_split(&ref);                                            // groups of 8 consecutive k of one row: [hi x8 | lo x8]
+    const uint16_t *fs = reinterpret_cast<const uint16_t *>(fsplit.data()), *rs = reinterpret_cast<const uint16_t *>(ref.data());
+    const int nkq = cmid / 16;
+    for (int j = 0; j < 4; ++j)
+      for (int wn = 0; wn < wgn; ++wn)
+        for (int kq = 0; kq < nkq; ++kq)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int e = 0; e < 8; ++e) {
+              const size_t n = (size_t)j * cmid + wn * 32 + (lane & 31), k0 = 16 * kq + 8 * (lane >> 5);
+              const size_t grp = (n * cmid + k0) / 8;                         // 8-element group index in to_split's layout
+              const size_t base = ((((size_t)j * wgn + wn) * (2 * nkq) + 2 * kq) * 64 + lane) * 8;
+              EXPECT(fs[base + e] == rs[grp * 16 + e]);
+              EXPECT(fs[base + 64 * 8 + e] == rs[grp * 16 + 8 + e]);
+            }
+  }
   // NaN / inf survive the bf16 conversion as NaN / inf (never as a finite number)
   EXPECT(std::isnan(bf2f(f2bf(std::nanf("")))));
   EXPECT(std::isinf(bf2f(f2bf(INFINITY))));
