@@ -279,7 +279,7 @@ def main():
         dom_kernel = 'conv_igemm<%s, %s, 3, false, false, %d, false, %s>' % (
             main_tile.replace('w8', '').replace('x', ', '), waves, prec_id, 'true' if args.dtype == 'f32' else 'false')
         if main_tile == '256x256':      # the LDS-DMA 256 x 256 bf16 kernel has its own name
-            dom_kernel = 'conv_bf16_256_kernel<3, false>'
+            dom_kernel = "conv_bf16_256_kernel<3, false, false, false>"
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         peak_name = ('dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); the kernel executes 3 MFMA FLOPs per algorithmic FLOP'
                      if args.dtype == 'bf16x3' else 'dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)' if args.dtype == 'bf16'
