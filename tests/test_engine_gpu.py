@@ -197,11 +197,23 @@ def test_c_program_runs_a_forward(hip_lib, tmp_path):
     ('bf16', 2, 8, 64, 64, 12, 5e-2),
     ('f32', 2, 8, 270, 480, 12, 1e-3),       # wide frames: many pooled tiles per row, ragged in both directions
     ('bf16x3', 2, 8, 270, 480, 12, 1e-3),
+    # the round-2 kernels forced on (the tuner would otherwise decide by timing): fused conv2 + conv3, 256 x 256 LDS-DMA tile
+    ('f32+fused', 3, 8, 64, 96, 2, 1e-3),
+    ('f32+fused', 4, 16, 96, 128, 5, 1e-3),
+    ('bf16x3+fused', 4, 8, 96, 64, 7, 1e-3),
+    ('bf16+256x256', 2, 8, 64, 64, 12, 5e-2),
+    ('bf16+256x256', 3, 8, 90, 70, 12, 5e-2),
 ])
-def test_unusual_configurations_against_oracle(hip_lib, dtype, t, div, h, w, ncls, rtol):
+def test_unusual_configurations_against_oracle(hip_lib, monkeypatch, dtype, t, div, h, w, ncls, rtol):
     """Segment counts, shift_div, class counts and aspect ratios other than the headline's, vs the CPU oracle."""
     from workoutdetector_amd.engine import TsmEngine
     from workoutdetector_amd.weights import make_state_dict, to_torch
+    dtype, _, force = dtype.partition('+')
+    if force == 'fused':
+        monkeypatch.setenv('TSM_FUSE_CONV23', '1')
+    elif force:
+        monkeypatch.setenv('TSM_AUTOTUNE', '0')
+        monkeypatch.setenv('TSM_CONV_TILE', force)
     sd = make_state_dict(7, ncls)
     eng = TsmEngine(num_class=ncls, num_segments=t, height=h, width=w, shift_div=div, max_clips=3, state_dict=sd,
                     dtype=dtype)
