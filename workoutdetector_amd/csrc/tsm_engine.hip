@@ -104,6 +104,10 @@ struct tsm_engine {
   // Tuning hooks, read ONCE in tsm_create (never per launch): TSM_CONV_TILE=<name> forces one tile shape wherever it
   // is valid, TSM_CONV_CODE=<int> one tile code (tile | 0x100 = split-K form); tests and tools/ sweeps only.
   int force_tile = 0, force_code = -1;
+  // Consecutive conv launches walk their output tiles in opposite directions: a kernel starts with the rows its
+  // predecessor wrote last, which are still in the Infinity Cache / L2 (bit-neutral; -1...2 % forward time in the
+  // HBM-bound formats, nothing in fp32).  TSM_ZIGZAG=0 switches it off.
+  bool zigzag = true;
   int fuse23 = -1;   // TSM_FUSE_CONV23: 0 never, 1 wherever a block is eligible, unset: the autotuner times both forms
   float last_tune_ms = 0.f;   // best time of the layer the tuner measured last (run_forward, tuning pass)
   int n_cu = 256;
@@ -335,7 +339,9 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   auto code_ok = [&](const tsm::ConvParams &p, int code) {
     return code > 0 && (code & ~0x50F) == 0 && tsm::conv_tile_valid(p, code & 15);   // (0x400: block runs fused, below)
   };
+  int flip = 0;   // alternates the tile walk direction of consecutive conv launches (ConvParams::reverse)
   auto conv = [&](int idx, tsm::ConvParams p, int ks, bool is3x3) -> int {
+    p.reverse = e->zigzag ? (flip ^= 1) : 0;
     if (!tuning) {
       int code = tiles ? (*tiles)[idx] : 0;
       if (e->force_tile) code = e->force_tile;
@@ -452,9 +458,11 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     if (can_fuse) {
       pf.x = t1; pf.w2 = c2.d_w; pf.bias2 = c2.d_b; pf.w3f = blk.d_w3f; pf.bias3 = c3.d_b; pf.res = identity; pf.y = y;
       pf.N = nn; pf.H = hh; pf.W = ww; pf.M = nn * hh * ww; pf.kseg_len = c2.kseg;
+      pf.reverse = e->zigzag ? (flip ^ 1) : 0;
     }
     if (can_fuse && !tuning && (e->fuse23 == 1 || (tiles && ((*tiles)[blk.conv2] & 0x400)))) {
       TSM_LAUNCH_K(e, s, true, tsm::launch_conv23_fused(pf, blk.cmid, prec, s));
+      flip ^= 1;
       if (e->cur_timing) {  // keep conv3's launch slot: reported as "not recorded"
         e->cur_timing->push_back(nullptr);
         e->cur_timing->push_back(nullptr);
@@ -572,6 +580,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (const char *ft = getenv("TSM_CONV_TILE")) e->force_tile = tsm::conv_tile_from_name(ft);
   if (const char *fc = getenv("TSM_CONV_CODE")) e->force_code = atoi(fc);
   if (const char *f23 = getenv("TSM_FUSE_CONV23")) e->fuse23 = atoi(f23) != 0;
+  if (const char *zz = getenv("TSM_ZIGZAG")) e->zigzag = atoi(zz) != 0;
   if (const char *tc = getenv("TSM_TUNE_CACHE")) {
     hipDeviceProp_t prop;
     e->tune_path = tc;

@@ -38,6 +38,9 @@ struct ConvParams {
   // bit-identical results: split-K for small batches without giving up batch invariance.
   int kseg_len;
   int ksplit;
+  // Walk the output tiles from the last one to the first.  The engine alternates this between consecutive launches:
+  // a kernel that starts with the rows its predecessor wrote LAST finds them in the 256-MB Infinity Cache / L2.
+  int reverse;
 };
 
 enum ConvPrec { kPrecF32 = 0, kPrecBf16x3 = 1, kPrecBf16 = 2 };
@@ -70,6 +73,7 @@ struct Fused23Params {
   int N, H, W;
   int M;               // N * H * W
   int kseg_len;        // conv2's K-segment length (ConvParams::kseg_len of that layer; 0 = unsegmented)
+  int reverse;         // walk the tiles from the last one to the first (ConvParams::reverse)
 };
 hipError_t launch_conv23_fused(const Fused23Params &p, int cmid, int prec, hipStream_t s);
 

@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && BM == 64) ? 5 : 1) con
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  if (p.reverse) tile = nwg - 1 - tile;   // walk the tiles from the far end (ConvParams::reverse)
   int seg = 0;  // SEG + ksplit: the grid holds ntm * ntn tiles per K segment, segment-major
   if (SEG && p.ksplit) {
     seg = tile / (p.ntm * p.ntn);
@@ -923,7 +924,8 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams 
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  if (p.reverse) tile = nwg - 1 - tile;
   const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
   const int m0 = tm * 256, n0 = tn * 256;
 
@@ -1215,7 +1217,8 @@ __global__ void __launch_bounds__(128 * (CMID / 32), 4) conv23_fused_kernel(cons
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  if (p.reverse) tile = nwg - 1 - tile;
   const int m0 = tile * 64;
 
   const int HW = p.H * p.W;
