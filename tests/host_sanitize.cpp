@@ -25,7 +25,7 @@ static int failures = 0;
 static void fuzz_tune_lines(unsigned seed, int rounds) {
   std::mt19937 rng(seed);
   const std::string want = "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|";
-  const int kNumTiles = 6;
+  const int kNumTiles = 7;
   // a well-formed line first
   {
     std::vector<int> codes(5, -1);

@@ -799,7 +799,7 @@ void conv_tile_shape(const ConvParams &p, int *bm, int *bn) {
 int conv_tile_from_name(const char *name) {
   if (!name) return kTileAuto;
   static const struct { const char *n; int t; } names[] = {{"128x128", kTile128x128}, {"128x64", kTile128x64},
-      {"64x64", kTile64x64}, {"32x32", kTile32x32}, {"128x128w8", kTile128x128w8}, {"256x256", kTile256x256}};
+      {"64x64", kTile64x64}, {"32x32", kTile32x32}, {"128x128w8", kTile128x128w8}, {"256x256", kTile256x256}, {"ws64", kTileWs64}};
   for (const auto &e : names)
     if (strcmp(name, e.n) == 0) return e.t;
   return kTileAuto;
@@ -815,16 +815,18 @@ bool conv_tile_valid(const ConvParams &p, int tile) {
     case kTile256x256:   // (ks is checked at launch: the stem has C == 4 and never qualifies)
       return p.prec == kPrecBf16 && p.Cout % 256 == 0 && p.C % 64 == 0 && !(p.res && p.x2) &&
              (!p.x2 || (p.K1 % 64 == 0 && p.C2 % 64 == 0));
+    case kTileWs64: return conv3x3_ws_valid(p);   // (pad == 1 singles out the 3x3 conv)
     default: return false;
   }
 }
 
 void conv_tile_dims(int tile, int *bm, int *bn) {
-  *bm = tile == kTile256x256 ? 256 : tile == kTile32x32 ? 32 : (tile == kTile64x64 ? 64 : 128);
+  *bm = (tile == kTile256x256 || tile == kTileWs64) ? 256 : tile == kTile32x32 ? 32 : (tile == kTile64x64 ? 64 : 128);
   *bn = tile == kTile256x256 ? 256 : tile == kTile32x32 ? 32 : ((tile == kTile128x128 || tile == kTile128x128w8) ? 128 : 64);
 }
 
 static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s);
+static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s);
 
 template <int KS, bool SHIFT, bool RES>
 static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
@@ -837,6 +839,10 @@ static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
   }
   if (p.tile == kTile256x256) {
     if constexpr (KS != 7) return launch_conv_bf16_256(p, KS, s);
+    else return hipErrorInvalidValue;
+  }
+  if (p.tile == kTileWs64) {
+    if constexpr (KS == 3) return launch_conv3x3_ws(p, s);
     else return hipErrorInvalidValue;
   }
   if (p.kseg_len > 0 && !(bm == 32 && bn == 32)) {  // segmented accumulation exists on 64x64 / 32x32 tiles only
@@ -1173,6 +1179,245 @@ static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s) {
   else if (p.res) hipLaunchKernelGGL((conv_bf16_256_kernel<1, false, true, false>), grid, block, kLdsBytes, s, p);
   else if (p.x2) hipLaunchKernelGGL((conv_bf16_256_kernel<1, false, false, true>), grid, block, kLdsBytes, s, p);
   else hipLaunchKernelGGL((conv_bf16_256_kernel<1, false>), grid, block, kLdsBytes, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv3x3_ws: the bf16 3x3 (stride 1, pad 1) convolution with 64 input and 64 output channels -- Bottleneck.conv2 of
+// layer1 -- as a WEIGHT-STATIONARY direct convolution.
+//
+// Why: with Cout = 64 an LDS-staged implicit GEMM reads (TM + TN) fragments per TM x TN MFMAs with TN <= 2; the
+// 128 x 64 tile of conv_igemm needs 1.5 ds_read_b128 per MFMA (one per MFMA already saturates the LDS port: four SIMDs x
+// 1 KiB per 32-cycle MFMA = 128 B/clk) and re-stages every input pixel nine times: 0.20 of the bf16 MFMA peak in
+// profiles/r02_bf16_config5_per_layer.txt, the slowest launches of the config-5 forward after the stem.  Here:
+//   * ONE workgroup of four waves per CU (one wave per SIMD, the whole 512-register file each), persistent over tiles;
+//     every wave keeps ALL of W2 -- 64 x 576 bf16 = 72 fragments = 288 registers -- for the life of the kernel, so the
+//     only LDS reads are the pixel fragments: 0.5 ds_read_b128 per MFMA, no weight traffic at all after the prologue;
+//   * the input of a tile of TR x TC output pixels (<= 256) is its (TR + 2) x (TC + 2) halo patch, brought in ONCE by
+//     LDS-DMA (`buffer_load ... lds`, 8 pixels = 1 KiB per wave-instruction, zero padding by the descriptor's range
+//     check / an out-of-range offset) into one of two buffers: the patch of tile i + 1 lands while tile i is computed;
+//     all nine taps read it from LDS -- no im2col re-staging.  A pixel's eight 16-byte chunks are XOR-swizzled by
+//     (patch index & 7) on the SOURCE side; the fragment reads apply the same involution (conflict-free ds_read_b128);
+//   * the product is computed TRANSPOSED -- A = weights (rows = output channels), B = pixels (columns) -- so a lane ends
+//     up with ONE pixel and 16 channels in groups of four: after bias / ReLU / bf16 two `v_permlane32_swap` per group
+//     pair make whole 16-byte channel groups, stored straight from registers (no LDS round trip in the epilogue);
+//   * one barrier per tile; the DMA of the next patch is retired (vmcnt) just before the last stores of the tile are
+//     issued, so no wait ever sees a store it has just issued.
+// Per output the products enter the fp32 accumulator in conv_igemm's order (taps ascending, k16 groups ascending, the
+// same eight k per lane half; a*b commutes), so results are bit-identical to the other bf16 tiles.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWsRounds = 13;                    // DMA rounds of 32 patch pixels (4 waves x 8 pixels)
+constexpr int kWsPatchMax = kWsRounds * 32;      // 416 patch pixels per buffer
+constexpr int kWsPlane = kWsPatchMax * 32;      // one k16 group of every patch pixel
+constexpr int kWsBufBytes = 4 * kWsPlane;        // 53 248 B; two buffers
+constexpr int kWsLdsBytes = 2 * kWsBufBytes + 256;
+constexpr int kWsAgprFrags1 = 20;                // fragments of the second output-channel tile kept in accumulation registers
+
+// Tile geometry for an H x W frame: TR x TC <= 256 output pixels, (TR + 2) x (TC + 2) <= kWsPatchMax patch pixels,
+// fewest tiles per frame (ties: the smaller patch).  Returns false when nothing fits.
+static bool ws_tile_geometry(int H, int W, int *tr_out, int *tc_out) {
+  long best_tiles = -1;
+  int best_tr = 0, best_tc = 0, best_patch = 0;
+  for (int tc = 4; tc <= 128; ++tc) {
+    int tr = 256 / tc;
+    if (tr > H) tr = H;
+    if (tr < 1) continue;
+    const int patch = (tr + 2) * (tc + 2);
+    if (patch > kWsPatchMax) continue;
+    const long tiles = (long)((H + tr - 1) / tr) * ((W + tc - 1) / tc);
+    if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && patch < best_patch)) {
+      best_tiles = tiles; best_tr = tr; best_tc = tc; best_patch = patch;
+    }
+  }
+  *tr_out = best_tr;
+  *tc_out = best_tc;
+  return best_tiles > 0;
+}
+
+__global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x kWsBufBytes, then the 64 biases
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int H = p.Hi, W = p.Wi, TR = p.ws_tr, TC = p.ws_tc, PW = TC + 2;
+  const int nr = ((TR + 2) * PW + 31) >> 5;                             // DMA rounds in use (<= kWsRounds)
+  const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR, tiles_f = tiles_x * tiles_y;
+  const int ntiles = p.N * tiles_f;
+  const int frame_bytes = H * W * 128;
+
+  // ---- the stationary operand: fragment s = tap * 4 + g of output-channel tile nt, k = 16 s + 8 half .. + 8.
+  // 56 of the 72 fragments are pinned to the accumulation-register half of the file (MFMA reads them there directly).
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 64 * p.Kp * 2, 0x00020000);
+  u32x4 wr[2][36];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int s = 0; s < 36; ++s)
+      wr[nt][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, ((nt * 32 + l31) * p.Kp + s * 16 + half * 8) * 2, 0, 0);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int s = 0; s < 36; ++s)
+      if (nt == 0 || s < kWsAgprFrags1) asm volatile("" : "+a"(wr[nt][s]));
+  float *bias_lds = reinterpret_cast<float *>(lds + 2 * kWsBufBytes);
+  if (tid < 64) bias_lds[tid] = p.bias[tid];
+  const float floor_ = p.relu ? 0.f : -INFINITY;
+
+  // ---- loader state.  A buffer is four planes, one per k16 group g: plane g holds bytes [32 g, 32 g + 32) of every patch
+  // pixel, 32 B per pixel, the two 16-byte halves swapped where (pixel >> 3) is odd.  Wave w fills plane w: in round i
+  // its lane fills half (lane & 1) of patch pixel 32 i + (lane >> 1).
+  const int chunk = 2 * wave + ((lane & 1) ^ ((lane >> 4) & 1));        // source chunk of that half
+  unsigned dslot[kWsRounds];                                            // (byte offset of the chunk relative to the patch origin) >> 4 | patch column << 24
+#pragma unroll
+  for (int i = 0; i < kWsRounds; ++i) {
+    const int pidx = 32 * i + (lane >> 1);
+    const int pr = pidx / PW, pc = pidx - pr * PW;
+    dslot[i] = (unsigned)((pr * W + pc) * 8 + chunk) | ((unsigned)pc << 24);
+  }
+  auto issue_patch = [&](int t, int b) {
+    const int f = t / tiles_f, rem = t - f * tiles_f;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int x0 = tx * TC;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)f * frame_bytes), 0, frame_bytes, 0x00020000);
+    const int tbase = ((ty * TR - 1) * W + (x0 - 1)) * 128;             // rows above / below the frame fall outside the descriptor: zeros
+    unsigned char *dst = lds + b * kWsBufBytes + wave * kWsPlane;
+#pragma unroll
+    for (int i = 0; i < kWsRounds; ++i)
+      if (i < nr) {
+        const int xg = x0 - 1 + (int)(dslot[i] >> 24);
+        const unsigned off = (unsigned)tbase + ((dslot[i] & 0xFFFFFFu) << 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(dst + i * 1024), 16,
+                                                 (int)((unsigned)xg < (unsigned)W ? off : kInvalid), 0, 0, 0);
+      }
+  };
+
+  // ---- this lane's two output pixels (M-tile mt = 0, 1 of the wave): position in the tile and in the patch
+  int prow[2], pcol[2], pp0[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int q = wave * 64 + mt * 32 + l31;
+    const bool ok = q < TR * TC;
+    const int r = q / TC, c = q - r * TC;
+    prow[mt] = ok ? r : 0x4000;                                         // (a row no frame has: the store is dropped)
+    pcol[mt] = c;
+    pp0[mt] = ok ? r * PW + c : 0;
+  }
+  const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * 128), 0x00020000);
+
+  // Epilogue of one 32-pixel M-tile in ten pieces (they ride on the MFMA steps of the NEXT M-tile): lane = pixel,
+  // a[nt][4 q + j] = channel nt * 32 + 8 q + 4 half + j.  Pieces 0-3 / 5-8: bias, ReLU, bf16 of group q of nt = 0 / 1;
+  // pieces 4 / 9: lanes 0-31 take groups 0, 1 and lanes 32-63 groups 2, 3 of the pixel (two v_permlane32_swap per group
+  // pair bring the other half's words in) and store them as whole 16-byte groups.
+  unsigned pk[4][2];
+  auto epi_piece = [&](const f32x16 (&a)[2], int k, unsigned yoff) {
+    const int nt = k / 5, q = k - nt * 5;
+    if (q < 4) {
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_lds + nt * 32 + 8 * q + 4 * half);
+      pk[q][0] = pack_bf16(fmaxf(a[nt][4 * q] + b[0], floor_), fmaxf(a[nt][4 * q + 1] + b[1], floor_));
+      pk[q][1] = pack_bf16(fmaxf(a[nt][4 * q + 2] + b[2], floor_), fmaxf(a[nt][4 * q + 3] + b[3], floor_));
+    } else {
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+          const auto r2 = __builtin_amdgcn_permlane32_swap(pk[qq][w2], pk[qq + 2][w2], false, false);
+          pk[qq][w2] = r2[0];
+          pk[qq + 2][w2] = r2[1];
+        }
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(yoff + (unsigned)(nt * 64 + (2 * half + qq) * 16)), 0, 0);
+      }
+    }
+  };
+  auto out_off = [&](int tt, int mt) -> unsigned {                      // byte offset of this lane's pixel of tile tt, or dropped
+    const int f = tt / tiles_f, rem = tt - f * tiles_f;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int oy = ty * TR + prow[mt], ox = tx * TC + pcol[mt];
+    return (oy < H && ox < W) ? (unsigned)(((f * H + oy) * W + ox) * 128) : kInvalid;
+  };
+
+  // One M-tile: 36 steps (tap, g) of one pixel-fragment read (three steps ahead) and two MFMAs; the epilogue pieces of
+  // the PREVIOUS M-tile (accumulators `prev`) are spread over steps 2, 5, .., 29.
+  auto mtile = [&](const unsigned char *buf, int mt, f32x16 (&acc)[2], const f32x16 (&prev)[2], unsigned prev_off) {
+    u32x4 px[4];
+    unsigned tb = 0;
+    auto rd = [&](int s) {
+      const int tap = s >> 2, g = s & 3, ky = tap / 3, kx = tap - ky * 3;
+      if (g == 0) {
+        const int pp = pp0[mt] + ky * PW + kx;
+        tb = (unsigned)(pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4));
+      }
+      px[s & 3] = *reinterpret_cast<const u32x4 *>(buf + tb + g * kWsPlane);
+    };
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+    rd(0); rd(1); rd(2);
+#pragma unroll
+    for (int s = 0; s < 36; ++s) {
+      if (s + 3 < 36) rd(s + 3);
+      if (s >= 2 && s < 32 && (s - 2) % 3 == 0) epi_piece(prev, (s - 2) / 3, prev_off);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr[nt][s]), __builtin_bit_cast(bf16x8, px[s & 3]),
+                                                          acc[nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  f32x16 accA[2], accB[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accB[nt][e] = 0.f;
+  unsigned offB = kInvalid;                                             // nothing to store before the first tile
+  int t = blockIdx.x, nb = 0;
+  if (t < ntiles) issue_patch(p.reverse ? ntiles - 1 - t : t, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the weights and this wave's share of the first patch
+  for (; t < ntiles; t += gridDim.x, nb ^= 1) {
+    __builtin_amdgcn_s_barrier();      // every wave's share of this patch has landed; nobody still reads the other buffer
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) issue_patch(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
+    const int tt = p.reverse ? ntiles - 1 - t : t;
+    const unsigned char *buf = lds + nb * kWsBufBytes;
+    mtile(buf, 0, accA, accB, offB);                                    // (B = M-tile 1 of the previous tile)
+    const unsigned offA = out_off(tt, 0);
+    mtile(buf, 1, accB, accA, offA);
+    offB = out_off(tt, 1);
+    // the next patch is older than the eight stores this iteration issued: retire it, not them
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) epi_piece(accB, k, offB);                // M-tile 1 of the last tile
+}
+
+bool conv3x3_ws_valid(const ConvParams &p) {
+  int tr, tc;
+  return p.prec == kPrecBf16 && p.C == 64 && p.Cout == 64 && p.Kp == 576 && p.stride == 1 && p.pad == 1 && p.Hi == p.Ho &&
+         p.Wi == p.Wo && !p.res && !p.x2 && p.T == 0 && p.kseg_len == 0 && (double)p.M * 128.0 < 2.0e9 &&
+         ws_tile_geometry(p.Hi, p.Wi, &tr, &tc);
+}
+
+static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
+  if (!conv3x3_ws_valid(p)) return hipErrorInvalidValue;
+  ws_tile_geometry(p.Hi, p.Wi, &p.ws_tr, &p.ws_tc);
+  const long ntiles = (long)p.N * ((p.Hi + p.ws_tr - 1) / p.ws_tr) * ((p.Wi + p.ws_tc - 1) / p.ws_tc);
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+               ? prop.multiProcessorCount : 256;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kWsLdsBytes);
+  }
+  const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);
+  hipLaunchKernelGGL(conv3x3_ws_kernel, dim3(grid), dim3(256), kWsLdsBytes, s, p);
   return hipGetLastError();
 }
 
