@@ -201,6 +201,8 @@ def test_c_program_runs_a_forward(hip_lib, tmp_path):
     ('f32+fused', 3, 8, 64, 96, 2, 1e-3),
     ('f32+fused', 4, 16, 96, 128, 5, 1e-3),
     ('bf16x3+fused', 4, 8, 96, 64, 7, 1e-3),
+    ('bf16+fused', 4, 8, 96, 64, 7, 5e-2),
+    ('bf16+fused', 3, 8, 90, 70, 12, 5e-2),
     ('bf16+256x256', 2, 8, 64, 64, 12, 5e-2),
     ('bf16+256x256', 3, 8, 90, 70, 12, 5e-2),
 ])
@@ -304,13 +306,15 @@ def test_tune_cache_file_round_trip(hip_lib, sd0, tmp_path, monkeypatch):
     assert len(path.read_text().splitlines()) == 2
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16x3'])
-@pytest.mark.parametrize('h,w,b', [(224, 224, 2), (96, 96, 3), (90, 70, 1)])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16x3', 'bf16'])
+@pytest.mark.parametrize('h,w,b', [(224, 224, 2), (96, 96, 3), (90, 70, 1), (256, 256, 3)])
 def test_fused_conv2_conv3_equals_the_separate_kernels_bitwise(hip_lib, sd0, monkeypatch, h, w, b, dtype):
     """conv23_fused (Bottleneck.conv2 + bn2 + ReLU + conv3 + bn3 + residual + ReLU in one kernel, the mid tensor kept in
     LDS; layer1.1-2 and layer2.1-3 of an fp32 or split-bf16 engine) against the two separate launches: same k order, same segment
     sums, same epilogue arithmetic -> same bits, on block-output taps and logits, including ragged last tiles
-    (90x70: 414 / 108 pixels per frame) and the segmented-K layer2 convs."""
+    (90x70: 414 / 108 pixels per frame) and the segmented-K layer2 convs.  bf16: the weight-stationary form
+    (conv3x3_ws_kernel<true>, layer1.1-2 only; the mid tensor stays in registers); 256x256 with 3 clips = 384 tiles,
+    more than one per persistent workgroup."""
     from workoutdetector_amd.engine import TsmEngine
     x = make_input(80 + h, b, 8, h, w)
     got = {}

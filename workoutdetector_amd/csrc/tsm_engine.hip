@@ -55,6 +55,7 @@ struct Block {
   int ksegf = 0;  // segment length of the fused GEMM
   // conv2 + conv3 (+ residual) as ONE kernel (tsm::launch_conv23_fused): fp32 / split-bf16 blocks without a downsample branch whose
   // mid tensor has 64 / 128 channels (layer1.1-2, layer2.1-3); d_w3f = conv3's folded weights in fragment order
+  // (fp32 / split-bf16; the bf16 form, 64 channels only, reads conv3's own packed matrix: d_w3f stays null, cmid = 64)
   float *d_w3f = nullptr;
   int cmid = 0;
 };
@@ -454,9 +455,10 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     // conv2 + conv3 + residual in one kernel where the block is eligible: bit 0x400 of conv2's tile code (set by the
     // tuning pass when the fused launch beat the two separate ones), or forced / forbidden through TSM_FUSE_CONV23
     tsm::Fused23Params pf{};
-    const bool can_fuse = blk.d_w3f != nullptr && e->fuse23 != 0 && !want(name + ".conv2");
+    const bool ws23 = prec == tsm::kPrecBf16 && blk.cmid == 64 && tsm::conv23_ws_valid(nn, hh, ww);
+    const bool can_fuse = (blk.d_w3f != nullptr || ws23) && e->fuse23 != 0 && !want(name + ".conv2");
     if (can_fuse) {
-      pf.x = t1; pf.w2 = c2.d_w; pf.bias2 = c2.d_b; pf.w3f = blk.d_w3f; pf.bias3 = c3.d_b; pf.res = identity; pf.y = y;
+      pf.x = t1; pf.w2 = c2.d_w; pf.bias2 = c2.d_b; pf.w3f = ws23 ? c3.d_w : blk.d_w3f; pf.bias3 = c3.d_b; pf.res = identity; pf.y = y;
       pf.N = nn; pf.H = hh; pf.W = ww; pf.M = nn * hh * ww; pf.kseg_len = c2.kseg;
       pf.reverse = e->zigzag ? (flip ^ 1) : 0;
     }
@@ -701,7 +703,11 @@ int tsm_finalize(tsm_engine *e) {
   // fragment order of the fused conv2 + conv3 kernel (fp32 and split-bf16 engines).
   for (Block &blk : e->blocks) {
     const ConvLayer &c2 = e->convs[blk.conv2], &c3 = e->convs[blk.conv3];
-    if (e->prec == tsm::kPrecBf16 || blk.down >= 0 || blk.stride != 1 || (c2.cout != 64 && c2.cout != 128)) continue;
+    if (blk.down >= 0 || blk.stride != 1 || (c2.cout != 64 && c2.cout != 128)) continue;
+    if (e->prec == tsm::kPrecBf16) {   // weight-stationary form: 64 mid channels only; it reads conv3's packed matrix itself
+      if (c2.cout == 64 && c2.cin == 64 && c3.cout == 256) blk.cmid = 64;
+      continue;
+    }
     std::vector<float> w3f;
     if (e->prec == tsm::kPrecBf16x3) pack_w3_fragments_split(host_wp[blk.conv3].data(), c2.cout, &w3f);
     else pack_w3_fragments(host_wp[blk.conv3].data(), c2.cout, &w3f);

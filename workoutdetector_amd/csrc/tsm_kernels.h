@@ -41,7 +41,6 @@ struct ConvParams {
   // Walk the output tiles from the last one to the first.  The engine alternates this between consecutive launches:
   // a kernel that starts with the rows its predecessor wrote LAST finds them in the 256-MB Infinity Cache / L2.
   int reverse;
-  int ws_tr, ws_tc;  // conv3x3_ws_kernel: output tile rows / columns (set by its launcher)
 };
 
 enum ConvPrec { kPrecF32 = 0, kPrecBf16x3 = 1, kPrecBf16 = 2 };
@@ -65,7 +64,8 @@ bool conv3x3_ws_valid(const ConvParams &p);
 hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s);
 // Bottleneck.conv2 (3x3, stride 1, pad 1) + bn2 + ReLU + conv3 (1x1) + bn3 + residual + ReLU as ONE launch (fp32 or split-bf16),
 // for CMID = 64 / 128 (layer1 / layer2 blocks without a downsample branch).  Bit-identical to launch_conv(conv2)
-// followed by launch_conv(conv3 with residual).
+// followed by launch_conv(conv3 with residual).  prec == kPrecBf16: CMID = 64 only, on the weight-stationary kernel
+// (conv3x3_ws_kernel<true>); w3f is then conv3's packed weight matrix [256][64] bf16 itself (no fragment packing).
 struct Fused23Params {
   const float *x;      // conv2 input [N, H, W, CMID]
   const float *w2;     // [CMID][9 * CMID]  conv2 weights, K = (ky, kx, c), bn2 scale folded in
@@ -80,6 +80,8 @@ struct Fused23Params {
   int reverse;         // walk the tiles from the last one to the first (ConvParams::reverse)
 };
 hipError_t launch_conv23_fused(const Fused23Params &p, int cmid, int prec, hipStream_t s);
+// Does the bf16 form apply to n frames of h x w pixels?
+bool conv23_ws_valid(int n, int h, int w);
 
 // Stem (7x7 s2 p3, 3 -> 64) of the bf16 formats as a direct convolution from an LDS-resident pixel-pair patch; x is the
 // packed-pair input [n][hi][ceil(wi/2)][8], w the engine's packed stem weights [64][kp], y NHWC, all in `prec`'s format

@@ -1206,11 +1206,16 @@ static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s) {
 // Per output the products enter the fp32 accumulator in conv_igemm's order (taps ascending, k16 groups ascending, the
 // same eight k per lane half; a*b commutes), so results are bit-identical to the other bf16 tiles.
 // ---------------------------------------------------------------------------------------------
-constexpr int kWsRounds = 13;                    // DMA rounds of 32 patch pixels (4 waves x 8 pixels)
-constexpr int kWsPatchMax = kWsRounds * 32;      // 416 patch pixels per buffer
+constexpr int kWsRounds = 11;                    // DMA rounds of 32 patch pixels (4 waves x 8 pixels)
+constexpr int kWsPatchMax = kWsRounds * 32;      // 352 patch pixels per buffer (18 x 18 for a 16 x 16 tile, 6 x 58 for 4 x 56)
 constexpr int kWsPlane = kWsPatchMax * 32;      // one k16 group of every patch pixel
-constexpr int kWsBufBytes = 4 * kWsPlane;        // 53 248 B; two buffers
+constexpr int kWsBufBytes = 4 * kWsPlane;        // 45 056 B
 constexpr int kWsLdsBytes = 2 * kWsBufBytes + 256;
+constexpr int kWsTableOff = kWsBufBytes + 256 + 1024 + 32768;      // FUSE3: one patch buffer, bias2, bias3, conv3's weights in fragment order
+constexpr int kWsRingOff = kWsTableOff + kWsRounds * 1024;         // ... the loader's per-thread offset table
+constexpr int kWsSlots = 4;                                        // residual ring: slots of 4 KB (one 32-channel tile of the wave's 64 pixels) per wave
+constexpr int kWsLdsBytes3All = kWsRingOff + 4 * kWsSlots * 4096;  // 155 904 B
+static_assert(kWsLdsBytes3All <= 160 * 1024, "LDS budget of the fused weight-stationary kernel");
 constexpr int kWsAgprFrags1 = 20;                // fragments of the second output-channel tile kept in accumulation registers
 
 // Tile geometry for an H x W frame: TR x TC <= 256 output pixels, (TR + 2) x (TC + 2) <= kWsPatchMax patch pixels,
@@ -1234,13 +1239,60 @@ static bool ws_tile_geometry(int H, int W, int *tr_out, int *tc_out) {
   return best_tiles > 0;
 }
 
-__global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const ConvParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x kWsBufBytes, then the 64 biases
+// `s_waitcnt vmcnt(n)` for a compile-time-foldable n (the instruction takes an immediate).
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define TSM_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    TSM_VMCNT_CASE(0) TSM_VMCNT_CASE(4) TSM_VMCNT_CASE(8) TSM_VMCNT_CASE(12) TSM_VMCNT_CASE(16) TSM_VMCNT_CASE(20)
+    TSM_VMCNT_CASE(24) TSM_VMCNT_CASE(28) TSM_VMCNT_CASE(32) TSM_VMCNT_CASE(36) TSM_VMCNT_CASE(40) TSM_VMCNT_CASE(44)
+    TSM_VMCNT_CASE(48) TSM_VMCNT_CASE(52) TSM_VMCNT_CASE(56) TSM_VMCNT_CASE(60)
+    TSM_VMCNT_CASE(3) TSM_VMCNT_CASE(7) TSM_VMCNT_CASE(11) TSM_VMCNT_CASE(15) TSM_VMCNT_CASE(19) TSM_VMCNT_CASE(23)
+    TSM_VMCNT_CASE(27) TSM_VMCNT_CASE(31) TSM_VMCNT_CASE(35) TSM_VMCNT_CASE(39) TSM_VMCNT_CASE(43) TSM_VMCNT_CASE(47)
+    TSM_VMCNT_CASE(51) TSM_VMCNT_CASE(55) TSM_VMCNT_CASE(59) TSM_VMCNT_CASE(63)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef TSM_VMCNT_CASE
+}
+// Vector-memory operations of the fused kernel's conv3 phase that are younger than the ring fill R_it when tile `it`
+// waits for it.  Issue order with D = kWsSlots:  R_0 .. R_{D-1} | P (kWsRounds) | [it = 0: wait, R_D, S_0] [1: wait,
+// R_{D+1}, S_1] ..., R = 4 fills of one slot (only while it + D < 8), S = 4 stores.
+constexpr int ws_younger_than_fill(int it) {
+  int n = 0;
+  if (it < kWsSlots) n += (kWsSlots - 1 - it) * 4 + kWsRounds;         // the rest of the prologue fills, the patch
+  else n += 4;                                                          // S_{it - D}, issued right after R_it
+  for (int i = (it < kWsSlots ? 0 : it - kWsSlots + 1); i < it; ++i) n += (i + kWsSlots < 8 ? 4 : 0) + 4;
+  return n;
+}
+
+// One parameter block for both forms of the kernel: FUSE3 = false, the 3x3 conv alone (y = [M][64]); FUSE3 = true,
+// Bottleneck.conv2 + bn2 + ReLU + conv3 + bn3 + residual + ReLU (y, res = [M][256]).
+struct WsParams {
+  const void *x;       // [N, H, W, 64] bf16
+  const void *w2;      // [64][576] bf16, K = (ky, kx, c), BN scale folded in
+  const float *bias2;  // [64]
+  const void *w3;      // FUSE3: [256][64] bf16 (conv3's packed weights, row-major)
+  const float *bias3;  // FUSE3: [256]
+  const void *res;     // FUSE3: [M, 256] bf16, the block input
+  void *y;
+  int N, H, W, M, relu, reverse, tr, tc;
+};
+
+// FUSE3: conv3 rides behind conv2 in the same registers.  With the transposed product a lane of conv2's accumulator
+// holds ONE pixel and 4 consecutive mid channels per group; after bias / ReLU / bf16 one v_permlane32_swap per word
+// pairs the two lane halves into 8 consecutive channels = exactly the B fragment (k16 group) of the next MFMA: the
+// 64-channel mid tensor never leaves the register file (no LDS, no HBM).  conv3 is again transposed (A = W3 fragments,
+// read from an LDS copy in fragment order: one read feeds the MFMAs of both M-tiles of the wave), its epilogue adds
+// bias3 and the residual in the accumulator layout (the residual arrives as 16-byte groups and goes through the same
+// swap backwards), and stores 16-byte groups.  Same products in the same order per accumulator as the two separate
+// launches (conv3: k16 groups ascending over its 64 channels), same epilogue arithmetic: bit-identical to them.
+template <bool FUSE3>
+__global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const WsParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x kWsBufBytes | bias2 | (FUSE3: bias3 | W3 fragments)
   typedef __attribute__((address_space(3))) void lds_void;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int H = p.Hi, W = p.Wi, TR = p.ws_tr, TC = p.ws_tc, PW = TC + 2;
+  const int H = p.H, W = p.W, TR = p.tr, TC = p.tc, PW = TC + 2;
   const int nr = ((TR + 2) * PW + 31) >> 5;                             // DMA rounds in use (<= kWsRounds)
   const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR, tiles_f = tiles_x * tiles_y;
   const int ntiles = p.N * tiles_f;
@@ -1248,32 +1300,50 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const ConvParams p) 
 
   // ---- the stationary operand: fragment s = tap * 4 + g of output-channel tile nt, k = 16 s + 8 half .. + 8.
   // 56 of the 72 fragments are pinned to the accumulation-register half of the file (MFMA reads them there directly).
-  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 64 * p.Kp * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w2), 0, 64 * 576 * 2, 0x00020000);
   u32x4 wr[2][36];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int s = 0; s < 36; ++s)
-      wr[nt][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, ((nt * 32 + l31) * p.Kp + s * 16 + half * 8) * 2, 0, 0);
+      wr[nt][s] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, ((nt * 32 + l31) * 576 + s * 16 + half * 8) * 2, 0, 0);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int s = 0; s < 36; ++s)
       if (nt == 0 || s < kWsAgprFrags1) asm volatile("" : "+a"(wr[nt][s]));
-  float *bias_lds = reinterpret_cast<float *>(lds + 2 * kWsBufBytes);
-  if (tid < 64) bias_lds[tid] = p.bias[tid];
-  const float floor_ = p.relu ? 0.f : -INFINITY;
+  // LDS: !FUSE3  two patch buffers | bias2;   FUSE3  one patch buffer | bias2 | bias3 | W3 fragments | loader table | residual rings
+  float *bias_lds = reinterpret_cast<float *>(lds + (FUSE3 ? 1 : 2) * kWsBufBytes);
+  float *bias3_lds = bias_lds + 64;
+  unsigned char *w3_lds = lds + kWsBufBytes + 256 + 1024;               // [it * 4 + g][lane] 16 B: conv3's A fragments
+  if (tid < 64) bias_lds[tid] = p.bias2[tid];
+  if constexpr (FUSE3) {
+    bias3_lds[tid] = p.bias3[tid];
+    const __amdgpu_buffer_rsrc_t rsrcW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w3), 0, 256 * 64 * 2, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int f = wave * 8 + k, it = f >> 2, g = f & 3;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcW3, ((32 * it + l31) * 64 + 16 * g + 8 * half) * 2, 0, 0);
+      *reinterpret_cast<u32x4 *>(w3_lds + f * 1024 + lane * 16) = v;
+    }
+  }
+  const float floor_ = (FUSE3 || p.relu) ? 0.f : -INFINITY;
 
   // ---- loader state.  A buffer is four planes, one per k16 group g: plane g holds bytes [32 g, 32 g + 32) of every patch
   // pixel, 32 B per pixel, the two 16-byte halves swapped where (pixel >> 3) is odd.  Wave w fills plane w: in round i
   // its lane fills half (lane & 1) of patch pixel 32 i + (lane >> 1).
   const int chunk = 2 * wave + ((lane & 1) ^ ((lane >> 4) & 1));        // source chunk of that half
-  unsigned dslot[kWsRounds];                                            // (byte offset of the chunk relative to the patch origin) >> 4 | patch column << 24
+  // per round: (byte offset of the chunk relative to the patch origin) >> 4 | patch column << 24 -- in registers, or
+  // (FUSE3, whose conv3 phase needs them for other things) in a per-thread LDS table
+  unsigned dslot[FUSE3 ? 1 : kWsRounds];
+  unsigned *dslot_lds = reinterpret_cast<unsigned *>(lds + kWsTableOff) + tid;
 #pragma unroll
   for (int i = 0; i < kWsRounds; ++i) {
     const int pidx = 32 * i + (lane >> 1);
     const int pr = pidx / PW, pc = pidx - pr * PW;
-    dslot[i] = (unsigned)((pr * W + pc) * 8 + chunk) | ((unsigned)pc << 24);
+    const unsigned v = (unsigned)((pr * W + pc) * 8 + chunk) | ((unsigned)pc << 24);
+    if constexpr (FUSE3) dslot_lds[i * 256] = v;
+    else dslot[i] = v;
   }
   auto issue_patch = [&](int t, int b) {
     const int f = t / tiles_f, rem = t - f * tiles_f;
@@ -1286,11 +1356,33 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const ConvParams p) 
 #pragma unroll
     for (int i = 0; i < kWsRounds; ++i)
       if (i < nr) {
-        const int xg = x0 - 1 + (int)(dslot[i] >> 24);
-        const unsigned off = (unsigned)tbase + ((dslot[i] & 0xFFFFFFu) << 4);
+        const unsigned ds = FUSE3 ? dslot_lds[i * 256] : dslot[FUSE3 ? 0 : i];
+        const int xg = x0 - 1 + (int)(ds >> 24);
+        const unsigned off = (unsigned)tbase + ((ds & 0xFFFFFFu) << 4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(dst + i * 1024), 16,
                                                  (int)((unsigned)xg < (unsigned)W ? off : kInvalid), 0, 0, 0);
       }
+  };
+
+  // FUSE3: the same with a CONSTANT number of operations (rounds past the patch, or t < 0 = no next tile, fetch nothing:
+  // an out-of-range offset writes zeros) -- its counted waits depend on it; always into the one buffer.
+  auto issue_patch_full = [&](int t) {
+    const int tq = t < 0 ? 0 : t;
+    const int f = tq / tiles_f, rem = tq - f * tiles_f;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int x0 = tx * TC;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)f * frame_bytes), 0, frame_bytes, 0x00020000);
+    const int tbase = ((ty * TR - 1) * W + (x0 - 1)) * 128;
+    unsigned char *dst = lds + wave * kWsPlane;
+#pragma unroll
+    for (int i = 0; i < kWsRounds; ++i) {
+      const unsigned ds = dslot_lds[i * 256];
+      const int xg = x0 - 1 + (int)(ds >> 24);
+      const unsigned off = (unsigned)tbase + ((ds & 0xFFFFFFu) << 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(dst + i * 1024), 16,
+                                               (int)((t >= 0 && i < nr && (unsigned)xg < (unsigned)W) ? off : kInvalid), 0, 0, 0);
+    }
   };
 
   // ---- this lane's two output pixels (M-tile mt = 0, 1 of the wave): position in the tile and in the patch
@@ -1304,19 +1396,29 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const ConvParams p) 
     pcol[mt] = c;
     pp0[mt] = ok ? r * PW + c : 0;
   }
-  const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * 128), 0x00020000);
+  // !FUSE3: one descriptor over the whole output (stores of a tile are issued while the next one is computed)
+  const __amdgpu_buffer_rsrc_t rsrcYall = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * 128), 0x00020000);
 
-  // Epilogue of one 32-pixel M-tile in ten pieces (they ride on the MFMA steps of the NEXT M-tile): lane = pixel,
-  // a[nt][4 q + j] = channel nt * 32 + 8 q + 4 half + j.  Pieces 0-3 / 5-8: bias, ReLU, bf16 of group q of nt = 0 / 1;
-  // pieces 4 / 9: lanes 0-31 take groups 0, 1 and lanes 32-63 groups 2, 3 of the pixel (two v_permlane32_swap per group
-  // pair bring the other half's words in) and store them as whole 16-byte groups.
+  // The accumulators of one 32-pixel M-tile -> bf16, in ten pieces (they ride on the MFMA steps of the NEXT M-tile):
+  // lane = pixel, a[nt][4 q + j] = channel nt * 32 + 8 q + 4 half + j.  Pieces 0-3 / 5-8: bias, ReLU, bf16 of group q of
+  // nt = 0 / 1.  Pieces 4 / 9, !FUSE3: lanes 0-31 take groups 0, 1 and lanes 32-63 groups 2, 3 of the pixel (one
+  // v_permlane32_swap per word brings the other half's words in) and store them as whole 16-byte groups.  FUSE3: the
+  // swap pairs groups (0, 1) and (2, 3) instead: lanes 0-31 then hold channels 16 g' .. + 8 and lanes 32-63 channels
+  // 16 g' + 8 .. + 8 of k16 group g' = 2 nt, 2 nt + 1 -- conv3's B fragments, kept in `mid`.
   unsigned pk[4][2];
-  auto epi_piece = [&](const f32x16 (&a)[2], int k, unsigned yoff) {
+  auto epi_piece = [&](const f32x16 (&a)[2], int k, unsigned yoff, u32x4 *mid) {
     const int nt = k / 5, q = k - nt * 5;
     if (q < 4) {
       const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_lds + nt * 32 + 8 * q + 4 * half);
       pk[q][0] = pack_bf16(fmaxf(a[nt][4 * q] + b[0], floor_), fmaxf(a[nt][4 * q + 1] + b[1], floor_));
       pk[q][1] = pack_bf16(fmaxf(a[nt][4 * q + 2] + b[2], floor_), fmaxf(a[nt][4 * q + 3] + b[3], floor_));
+    } else if constexpr (FUSE3) {
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * qq][0], pk[2 * qq + 1][0], false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * qq][1], pk[2 * qq + 1][1], false, false);
+        mid[2 * nt + qq] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+      }
     } else {
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq)
@@ -1329,20 +1431,21 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const ConvParams p) 
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
         const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(yoff + (unsigned)(nt * 64 + (2 * half + qq) * 16)), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcYall, (int)(yoff + (unsigned)(nt * 64 + (2 * half + qq) * 16)), 0, 0);
       }
     }
   };
-  auto out_off = [&](int tt, int mt) -> unsigned {                      // byte offset of this lane's pixel of tile tt, or dropped
+  auto out_off = [&](int tt, int mt) -> unsigned {                      // !FUSE3: byte offset of this lane's pixel of tile tt, or dropped
     const int f = tt / tiles_f, rem = tt - f * tiles_f;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int oy = ty * TR + prow[mt], ox = tx * TC + pcol[mt];
     return (oy < H && ox < W) ? (unsigned)(((f * H + oy) * W + ox) * 128) : kInvalid;
   };
 
-  // One M-tile: 36 steps (tap, g) of one pixel-fragment read (three steps ahead) and two MFMAs; the epilogue pieces of
-  // the PREVIOUS M-tile (accumulators `prev`) are spread over steps 2, 5, .., 29.
-  auto mtile = [&](const unsigned char *buf, int mt, f32x16 (&acc)[2], const f32x16 (&prev)[2], unsigned prev_off) {
+  // One M-tile: 36 steps (tap, g) of one pixel-fragment read (three steps ahead) and two MFMAs; the pieces of the
+  // PREVIOUS M-tile (accumulators `prev`), if any, are spread over steps 2, 5, .., 29.
+  auto mtile = [&](const unsigned char *buf, int mt, f32x16 (&acc)[2], const f32x16 (&prev)[2], bool has_prev, unsigned prev_off,
+                   u32x4 *prev_mid) {
     u32x4 px[4];
     unsigned tb = 0;
     auto rd = [&](int s) {
@@ -1361,7 +1464,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const ConvParams p) 
 #pragma unroll
     for (int s = 0; s < 36; ++s) {
       if (s + 3 < 36) rd(s + 3);
-      if (s >= 2 && s < 32 && (s - 2) % 3 == 0) epi_piece(prev, (s - 2) / 3, prev_off);
+      if (has_prev && s >= 2 && s < 32 && (s - 2) % 3 == 0) epi_piece(prev, (s - 2) / 3, prev_off, prev_mid);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr[nt][s]), __builtin_bit_cast(bf16x8, px[s & 3]),
@@ -1375,25 +1478,156 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const ConvParams p) 
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) accB[nt][e] = 0.f;
-  unsigned offB = kInvalid;                                             // nothing to store before the first tile
   int t = blockIdx.x, nb = 0;
   if (t < ntiles) issue_patch(p.reverse ? ntiles - 1 - t : t, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the weights and this wave's share of the first patch
-  for (; t < ntiles; t += gridDim.x, nb ^= 1) {
-    __builtin_amdgcn_s_barrier();      // every wave's share of this patch has landed; nobody still reads the other buffer
-    const int tn = t + gridDim.x;
-    if (tn < ntiles) issue_patch(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
-    const int tt = p.reverse ? ntiles - 1 - t : t;
-    const unsigned char *buf = lds + nb * kWsBufBytes;
-    mtile(buf, 0, accA, accB, offB);                                    // (B = M-tile 1 of the previous tile)
-    const unsigned offA = out_off(tt, 0);
-    mtile(buf, 1, accB, accA, offA);
-    offB = out_off(tt, 1);
-    // the next patch is older than the eight stores this iteration issued: retire it, not them
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");           // the weights, this wave's share of the first patch, its LDS fills
+
+  if constexpr (!FUSE3) {
+    unsigned offB = kInvalid;                                           // nothing to store before the first tile
+    for (; t < ntiles; t += gridDim.x, nb ^= 1) {
+      __builtin_amdgcn_s_barrier();    // every wave's share of this patch has landed; nobody still reads the other buffer
+      const int tn = t + gridDim.x;
+      if (tn < ntiles) issue_patch(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
+      const int tt = p.reverse ? ntiles - 1 - t : t;
+      const unsigned char *buf = lds + nb * kWsBufBytes;
+      mtile(buf, 0, accA, accB, true, offB, nullptr);                   // (B = M-tile 1 of the previous tile)
+      const unsigned offA = out_off(tt, 0);
+      mtile(buf, 1, accB, accA, true, offA, nullptr);
+      offB = out_off(tt, 1);
+      // the next patch is older than the eight stores this iteration issued: retire it, not them
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
 #pragma unroll
-  for (int k = 0; k < 10; ++k) epi_piece(accB, k, offB);                // M-tile 1 of the last tile
+    for (int k = 0; k < 10; ++k) epi_piece(accB, k, offB, nullptr);     // M-tile 1 of the last tile
+  } else {
+    // FUSE3 uses ONE patch buffer (the conv3 phase does not read it: the next patch is fetched under that phase) and
+    // spends the LDS on a wave-private ring of kWsSlots residual slots, filled by LDS-DMA that many output-channel
+    // tiles ahead of their use: 16 KB of residual in flight per wave without a register.  A slot holds the wave's 64 pixels x
+    // 64 B (one tile of 32 channels); chunk c of pixel x sits at 16-byte position (c + (x >> 2)) & 3 of its row (swizzle
+    // on the source side; the ds_read_b64 of the accumulator layout -- lane = pixel, 4 channels -- is conflict-free).
+    const int frame_out = H * W * 512;
+    unsigned char *ring = lds + kWsRingOff + wave * (kWsSlots * 4096);
+    // loader lanes of the ring: lane fills position (lane & 3) of pixel 16 j + (lane >> 2), j = 0..3
+    const int rchunk = ((lane & 3) - (lane >> 4)) & 3;
+    int drc[4];                                                         // that pixel's tile row | column << 16 (row 0x4000: not in the tile)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = wave * 64 + 16 * j + (lane >> 2);
+      const int r = q / TC, c = q - r * TC;
+      drc[j] = (q < TR * TC ? r : 0x4000) | (c << 16);
+    }
+    unsigned rrd[2];                                                    // read offset of this lane's pixel of M-tile mt, group q = 0 (+ 16 ((q + s) & 3) - 16 s per q)
+    const int rsw = (l31 >> 2) & 3;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) rrd[mt] = (unsigned)((mt * 32 + l31) * 64 + half * 8);
+    for (; t < ntiles; t += gridDim.x) {
+      const int tt = p.reverse ? ntiles - 1 - t : t;
+      const int f = tt / tiles_f, rem = tt - f * tiles_f;
+      const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+      const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(reinterpret_cast<const char *>(p.res) + (size_t)f * frame_out), 0, frame_out, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<char *>(p.y) + (size_t)f * frame_out, 0, frame_out, 0x00020000);
+      unsigned yo[2], ro[4];       // byte offset of the 256 channels of: this lane's pixel of M-tile mt / its loader pixel j (+ its chunk)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int oy = ty * TR + prow[mt], ox = tx * TC + pcol[mt];
+        yo[mt] = (oy < H && ox < W) ? (unsigned)((oy * W + ox) * 512) : kInvalid;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int oy = ty * TR + (drc[j] & 0xFFFF), ox = tx * TC + (drc[j] >> 16);
+        ro[j] = (oy < H && ox < W) ? (unsigned)((oy * W + ox) * 512 + rchunk * 16) : kInvalid;
+      }
+      auto issue_res = [&](int it) {                                    // 4 vector-memory operations
+        unsigned char *dst = ring + (it % kWsSlots) * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcR, (lds_void *)(dst + j * 1024), 16,
+                                                   (int)(ro[j] == kInvalid ? kInvalid : ro[j] + (unsigned)(it * 64)), 0, 0, 0);
+      };
+      // (the eight youngest operations are stores of the previous tile; the patch is older)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();    // every wave's share of this patch has landed
+      #pragma unroll
+      for (int i = 0; i < kWsSlots; ++i) issue_res(i);
+      u32x4 mid[2][4];
+      mtile(lds, 0, accA, accB, false, 0u, nullptr);
+      mtile(lds, 1, accB, accA, true, 0u, mid[0]);
+#pragma unroll
+      for (int k = 0; k < 10; ++k) epi_piece(accB, k, 0u, mid[1]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();    // nobody reads the patch any more: fetch the next one under the conv3 phase
+      {                                // always kWsRounds operations (dead ones past the patch / past the last tile), so that the waits below count
+        const int tn = t + gridDim.x;
+        issue_patch_full(tn < ntiles ? (p.reverse ? ntiles - 1 - tn : tn) : -1);
+      }
+      // ---- conv3: eight tiles of 32 output channels, both M-tiles per W3 fragment; the wait of tile `it` leaves exactly
+      // the vector-memory operations younger than its ring fill in flight (ws_younger_than_fill)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        wait_vmcnt(ws_younger_than_fill(it));
+        // the residual in the accumulator layout: rp[mt][q] = channels it * 32 + 8 q + 4 half .. + 4 of this lane's pixel
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 rp[2][4];
+        const unsigned char *slot = ring + (it % kWsSlots) * 4096;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            rp[mt][q] = *reinterpret_cast<const u32x2 *>(slot + rrd[mt] + (((q + rsw) & 3) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the slot is free again
+        if (it + kWsSlots < 8) issue_res(it + kWsSlots);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 c3[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) c3[mt][e] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x8 wf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(w3_lds + (it * 4 + g) * 1024 + lane * 16));
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            c3[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8, mid[mt][g]), c3[mt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          // + bias3, + residual, ReLU, bf16; lanes 0-31 then take groups 0, 1 and lanes 32-63 groups 2, 3 of the pixel
+          // (v_permlane32_swap) and store them as 16-byte groups, straight from registers
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(bias3_lds + it * 32 + 8 * q + 4 * half);
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned w2 = rp[mt][q][j >> 1];
+              v[j] = c3[mt][4 * q + j] + b[j];
+              v[j] += __builtin_bit_cast(float, (j & 1) ? (w2 & 0xFFFF0000u) : (w2 << 16));
+              v[j] = fmaxf(v[j], 0.f);
+            }
+            pk[q][0] = pack_bf16(v[0], v[1]);
+            pk[q][1] = pack_bf16(v[2], v[3]);
+          }
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) {
+              const auto r2 = __builtin_amdgcn_permlane32_swap(pk[qq][w2], pk[qq + 2][w2], false, false);
+              pk[qq][w2] = r2[0];
+              pk[qq + 2][w2] = r2[1];
+            }
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
+            __builtin_amdgcn_raw_buffer_store_b128(
+                o, rsrcY, (int)(yo[mt] == kInvalid ? kInvalid : yo[mt] + (unsigned)(it * 64 + (2 * half + qq) * 16)), 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
 }
 
 bool conv3x3_ws_valid(const ConvParams &p) {
@@ -1403,21 +1637,48 @@ bool conv3x3_ws_valid(const ConvParams &p) {
          ws_tile_geometry(p.Hi, p.Wi, &tr, &tc);
 }
 
-static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
-  if (!conv3x3_ws_valid(p)) return hipErrorInvalidValue;
-  ws_tile_geometry(p.Hi, p.Wi, &p.ws_tr, &p.ws_tc);
-  const long ntiles = (long)p.N * ((p.Hi + p.ws_tr - 1) / p.ws_tr) * ((p.Wi + p.ws_tc - 1) / p.ws_tc);
+static int ws_grid_setup() {
   static int n_cu = 0;
   if (!n_cu) {
     hipDeviceProp_t prop;
     int dev = 0;
     n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                ? prop.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kWsLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kWsLdsBytes3All);
   }
-  const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);
-  hipLaunchKernelGGL(conv3x3_ws_kernel, dim3(grid), dim3(256), kWsLdsBytes, s, p);
+  return n_cu;
+}
+
+static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
+  if (!conv3x3_ws_valid(p)) return hipErrorInvalidValue;
+  WsParams q{};
+  q.x = p.x; q.w2 = p.w; q.bias2 = p.bias; q.y = p.y;
+  q.N = p.N; q.H = p.Hi; q.W = p.Wi; q.M = p.M; q.relu = p.relu; q.reverse = p.reverse;
+  ws_tile_geometry(q.H, q.W, &q.tr, &q.tc);
+  const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
+  const int n_cu = ws_grid_setup();
+  hipLaunchKernelGGL(conv3x3_ws_kernel<false>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kWsLdsBytes, s, q);
+  return hipGetLastError();
+}
+
+// Fused23Params with bf16 operands: w3f = conv3's packed weights [256][64] bf16 (row-major, as launch_conv takes them).
+bool conv23_ws_valid(int n, int h, int w) {
+  int tr, tc;
+  return n > 0 && h > 0 && w > 0 && (double)h * w * 512.0 < 2.0e9 && (double)n * h * w < 2.0e9 && ws_tile_geometry(h, w, &tr, &tc);
+}
+
+static hipError_t launch_conv23_ws(const Fused23Params &p, hipStream_t s) {
+  if (!conv23_ws_valid(p.N, p.H, p.W) || p.kseg_len != 0) return hipErrorInvalidValue;
+  WsParams q{};
+  q.x = p.x; q.w2 = p.w2; q.bias2 = p.bias2; q.w3 = p.w3f; q.bias3 = p.bias3; q.res = p.res; q.y = p.y;
+  q.N = p.N; q.H = p.H; q.W = p.W; q.M = p.M; q.relu = 1; q.reverse = p.reverse;
+  ws_tile_geometry(q.H, q.W, &q.tr, &q.tc);
+  const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
+  const int n_cu = ws_grid_setup();
+  hipLaunchKernelGGL(conv3x3_ws_kernel<true>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kWsLdsBytes3All, s, q);
   return hipGetLastError();
 }
 
@@ -1764,6 +2025,10 @@ __global__ void __launch_bounds__(128 * (CMID / 32), 4) conv23_fused_kernel(cons
 
 hipError_t launch_conv23_fused(const Fused23Params &p_in, int cmid, int prec, hipStream_t s) {
   Fused23Params p = p_in;
+  if (prec == kPrecBf16) {   // weight-stationary form (conv3x3_ws_kernel<true>): layer1's geometry only
+    if (cmid != 64 || !p.x || !p.w2 || !p.bias2 || !p.w3f || !p.bias3 || !p.res || !p.y || p.M != p.N * p.H * p.W) return hipErrorInvalidValue;
+    return launch_conv23_ws(p, s);
+  }
   if (prec != kPrecF32 && prec != kPrecBf16x3) return hipErrorInvalidValue;
   if (prec == kPrecBf16x3 && p.kseg_len != 0) return hipErrorInvalidValue;   // (only fp32 layers are segmented)
   if (!p.x || !p.w2 || !p.bias2 || !p.w3f || !p.bias3 || !p.res || !p.y) return hipErrorInvalidValue;
