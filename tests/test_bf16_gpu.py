@@ -95,7 +95,7 @@ def test_tile_choice_is_bitwise_neutral_in_bf16_modes(hip_lib, sd0, monkeypatch,
                       # arm; K-concatenated downsample arm in the first block of a stage), conv2 / conv1 of layer3-4
                       ('256x256', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '256x256'}),
                       # the weight-stationary 3x3 kernel where it applies (bf16, 64 -> 64 channels: conv2 of layer1)
-                      ('ws64', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': 'ws64'})]:
+                      ('ws', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': 'ws'})]:
         for k in ('TSM_AUTOTUNE', 'TSM_CONV_TILE'):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -183,31 +183,39 @@ def test_lds_dma_256_tile_equals_the_128_tiles_bitwise(hip_lib, monkeypatch, n, 
     assert_close(_nchw(outs['256x256']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='256x256 bf16')
 
 
-@pytest.mark.parametrize('n,hi,wi,relu', [
-    (16, 64, 64, True),     # layer1 at the config-5 size: 16 x 16 tiles, 256 tiles = one per workgroup
-    (40, 64, 64, True),     # 640 tiles: 2.5 per workgroup (double-buffered patches, ragged persistent tail)
-    (8, 56, 56, True),      # layer1 at 224^2: 4 x 56 tiles (224 of 256 lanes used), 112 tiles
-    (3, 23, 18, False),     # ragged in both directions, no ReLU
-    (5, 7, 5, True),        # a frame smaller than one tile
-    (2, 130, 9, True),      # narrow and tall
-    (1, 3, 200, True),      # wider than any tile: several tiles per row, frame shorter than a tile
-    (300, 8, 8, True),      # more frames than workgroups, one tile each
+@pytest.mark.parametrize('ch,n,hi,wi,relu', [
+    (64, 16, 64, 64, True),     # layer1 at the config-5 size: 16 x 16 tiles, 256 tiles = one per workgroup
+    (64, 40, 64, 64, True),     # 640 tiles: 2.5 per workgroup (double-buffered patches, ragged persistent tail)
+    (64, 8, 56, 56, True),      # layer1 at 224^2: 4 x 56 tiles (224 of 256 lanes used), 112 tiles
+    (64, 3, 23, 18, False),     # ragged in both directions, no ReLU
+    (64, 5, 7, 5, True),        # a frame smaller than one tile
+    (64, 2, 130, 9, True),      # narrow and tall
+    (64, 1, 3, 200, True),      # wider than any tile: several tiles per row, frame shorter than a tile
+    (64, 300, 8, 8, True),      # more frames than workgroups, one tile each
+    (128, 16, 32, 32, True),    # layer2 at the config-5 size: 8 x 16 tiles, 8 per frame
+    (128, 80, 32, 32, True),    # 640 tiles: 2.5 per workgroup
+    (128, 8, 28, 28, True),     # layer2 at 224^2: 4 x 28 tiles
+    (128, 3, 23, 18, False),    # ragged, no ReLU
+    (128, 5, 7, 5, True),       # a frame smaller than one tile
+    (128, 1, 3, 200, True),     # several tiles per row
+    (128, 300, 8, 8, True),     # more frames than workgroups
 ])
-def test_weight_stationary_3x3_equals_the_igemm_tiles_bitwise(hip_lib, monkeypatch, n, hi, wi, relu):
-    """conv3x3_ws_kernel (weights resident in registers, input patch by LDS-DMA, transposed MFMA, register epilogue through
+def test_weight_stationary_3x3_equals_the_igemm_tiles_bitwise(hip_lib, monkeypatch, ch, n, hi, wi, relu):
+    """conv3x3_ws_kernel / conv3x3_ws128_kernel (weights resident in registers -- all of W2 per wave for 64 channels, a
+    32-output-channel slice per wave for 128 --, input patch by LDS-DMA, transposed MFMA, register epilogue through
     v_permlane32_swap) against conv_igemm's bf16 tiles through the per-op entry point: same k order per output -> same
     bits; and against the fp32 oracle at the bf16 mode's tolerance."""
     from workoutdetector_amd.engine import conv_bn_act_nhwc
-    g = torch.Generator().manual_seed(9100 + n + hi + wi)
-    x = torch.randn(n, 64, hi, wi, generator=g)
-    w = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5
-    bn = _bn(64, g)
+    g = torch.Generator().manual_seed(9100 + ch + n + hi + wi)
+    x = torch.randn(n, ch, hi, wi, generator=g)
+    w = torch.randn(ch, ch, 3, 3, generator=g) * (2.0 / (9 * ch)) ** 0.5
+    bn = _bn(ch, g)
     outs = {}
-    for tile in ('ws64', '128x64', '64x64'):
+    for tile in ('ws', '128x64', '64x64'):
         monkeypatch.setenv('TSM_CONV_TILE', tile)
         outs[tile] = conv_bn_act_nhwc(_nhwc(x).cuda(), w.cuda(), *[b.cuda() for b in bn], stride=1, relu=relu, dtype='bf16').cpu()
     assert torch.equal(outs['64x64'], outs['128x64'])
-    assert torch.equal(outs['ws64'], outs['64x64'])
+    assert torch.equal(outs['ws'], outs['64x64'])
     if n * hi * wi <= 70000:
         want = tsm_oracle.conv_bn_act(x, w, bn, 1, 1, relu, None)
-        assert_close(_nchw(outs['ws64']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='ws64 bf16')
+        assert_close(_nchw(outs['ws']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='ws bf16')

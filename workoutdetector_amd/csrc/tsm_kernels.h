@@ -49,16 +49,17 @@ enum ConvTile {
   kTileAuto = 0, kTile128x128 = 1, kTile128x64 = 2, kTile64x64 = 3, kTile32x32 = 4,
   kTile128x128w8 = 5,  // 128x128 on 8 waves (512 threads): same LDS as kTile128x128, twice the waves per SIMD
   kTile256x256 = 6,    // conv_bf16_256_kernel: bf16 only, 8 waves, one workgroup per CU, operands by LDS-DMA
-  kTileWs64 = 7,       // conv3x3_ws_kernel: bf16 3x3 s1 p1 with C = Cout = 64, weights resident in registers, input patch by LDS-DMA
+  kTileWs = 7,       // conv3x3_ws[128]_kernel: bf16 3x3 s1 p1 with C = Cout = 64 / 128, weights resident in registers, input patch by LDS-DMA
   kNumTiles = 8
 };
 void conv_tile_dims(int tile, int *bm, int *bn);
-// "128x128" | "128x64" | "64x64" | "32x32" | "128x128w8" | "256x256" | "ws64" -> ConvTile (kTileAuto for anything else).
+// "128x128" | "128x64" | "64x64" | "32x32" | "128x128w8" | "256x256" | "ws" -> ConvTile (kTileAuto for anything else).
 int conv_tile_from_name(const char *name);
 // Is `tile` usable for this problem (Cout divisibility)?
 bool conv_tile_valid(const ConvParams &p, int tile);
-// Does the weight-stationary 3x3 kernel (kTileWs64) apply to this problem?
+// Do the weight-stationary 3x3 kernels (kTileWs: 64 -> 64 channels, or 128 -> 128) apply to this problem?
 bool conv3x3_ws_valid(const ConvParams &p);
+bool conv3x3_ws128_valid(const ConvParams &p);
 
 // ks in {1, 3, 7}.  Returns hipSuccess or the launch error.
 hipError_t launch_conv(const ConvParams &p, int ks, hipStream_t s);

@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 
 namespace tsm {
 
@@ -799,7 +800,7 @@ void conv_tile_shape(const ConvParams &p, int *bm, int *bn) {
 int conv_tile_from_name(const char *name) {
   if (!name) return kTileAuto;
   static const struct { const char *n; int t; } names[] = {{"128x128", kTile128x128}, {"128x64", kTile128x64},
-      {"64x64", kTile64x64}, {"32x32", kTile32x32}, {"128x128w8", kTile128x128w8}, {"256x256", kTile256x256}, {"ws64", kTileWs64}};
+      {"64x64", kTile64x64}, {"32x32", kTile32x32}, {"128x128w8", kTile128x128w8}, {"256x256", kTile256x256}, {"ws", kTileWs}};
   for (const auto &e : names)
     if (strcmp(name, e.n) == 0) return e.t;
   return kTileAuto;
@@ -815,13 +816,13 @@ bool conv_tile_valid(const ConvParams &p, int tile) {
     case kTile256x256:   // (ks is checked at launch: the stem has C == 4 and never qualifies)
       return p.prec == kPrecBf16 && p.Cout % 256 == 0 && p.C % 64 == 0 && !(p.res && p.x2) &&
              (!p.x2 || (p.K1 % 64 == 0 && p.C2 % 64 == 0));
-    case kTileWs64: return conv3x3_ws_valid(p);   // (pad == 1 singles out the 3x3 conv)
+    case kTileWs: return conv3x3_ws_valid(p) || conv3x3_ws128_valid(p);   // (pad == 1 singles out the 3x3 conv)
     default: return false;
   }
 }
 
 void conv_tile_dims(int tile, int *bm, int *bn) {
-  *bm = (tile == kTile256x256 || tile == kTileWs64) ? 256 : tile == kTile32x32 ? 32 : (tile == kTile64x64 ? 64 : 128);
+  *bm = (tile == kTile256x256 || tile == kTileWs) ? 256 : tile == kTile32x32 ? 32 : (tile == kTile64x64 ? 64 : 128);
   *bn = tile == kTile256x256 ? 256 : tile == kTile32x32 ? 32 : ((tile == kTile128x128 || tile == kTile128x128w8) ? 128 : 64);
 }
 
@@ -841,7 +842,7 @@ static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
     if constexpr (KS != 7) return launch_conv_bf16_256(p, KS, s);
     else return hipErrorInvalidValue;
   }
-  if (p.tile == kTileWs64) {
+  if (p.tile == kTileWs) {
     if constexpr (KS == 3) return launch_conv3x3_ws(p, s);
     else return hipErrorInvalidValue;
   }
@@ -1220,15 +1221,15 @@ constexpr int kWsAgprFrags1 = 20;                // fragments of the second outp
 
 // Tile geometry for an H x W frame: TR x TC <= 256 output pixels, (TR + 2) x (TC + 2) <= kWsPatchMax patch pixels,
 // fewest tiles per frame (ties: the smaller patch).  Returns false when nothing fits.
-static bool ws_tile_geometry(int H, int W, int *tr_out, int *tc_out) {
+static bool ws_tile_geometry(int H, int W, int *tr_out, int *tc_out, int max_px = 256, int max_patch = kWsPatchMax) {
   long best_tiles = -1;
   int best_tr = 0, best_tc = 0, best_patch = 0;
   for (int tc = 4; tc <= 128; ++tc) {
-    int tr = 256 / tc;
+    int tr = max_px / tc;
     if (tr > H) tr = H;
     if (tr < 1) continue;
     const int patch = (tr + 2) * (tc + 2);
-    if (patch > kWsPatchMax) continue;
+    if (patch > max_patch) continue;
     const long tiles = (long)((H + tr - 1) / tr) * ((W + tc - 1) / tc);
     if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && patch < best_patch)) {
       best_tiles = tiles; best_tr = tr; best_tc = tc; best_patch = patch;
@@ -1237,6 +1238,17 @@ static bool ws_tile_geometry(int H, int W, int *tr_out, int *tc_out) {
   *tr_out = best_tr;
   *tc_out = best_tc;
   return best_tiles > 0;
+}
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N - 1>) -- unrolled in the AST, for bodies too large for
+// `#pragma unroll` to honour (its size threshold silently leaves a loop, and the register arrays go to scratch).
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
 // `s_waitcnt vmcnt(n)` for a compile-time-foldable n (the instruction takes an immediate).
@@ -1630,6 +1642,189 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const WsParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv3x3_ws128: the weight-stationary form for 128 -> 128 channels (Bottleneck.conv2 of layer2, bf16).  W2 is
+// 128 x 1152 bf16 = 288 KB: no wave can hold it, so the OUTPUT CHANNELS are split over the four waves -- wave w keeps the
+// 72 fragments (288 registers) of channels 32 w .. 32 w + 31 for all of K -- and every wave walks ALL pixels of the
+// tile: 128 pixels = 4 M-tiles, two at a time (two independent accumulator chains), one pixel-fragment read per MFMA
+// (K is never split across waves: every output still accumulates its 1152 products in conv_igemm's order, bit-identical).
+// The rest is conv3x3_ws_kernel<false>: persistent workgroups, the (TR + 2) x (TC + 2) patch of 256-byte pixels by
+// LDS-DMA into one of two buffers of eight 32-byte planes (wave w fills planes 2 w, 2 w + 1), transposed MFMA, the
+// epilogue of a pair of M-tiles in ten pieces under the MFMA steps of the next pair, 16-byte groups stored from
+// registers (a wave writes its own 64-byte channel slice of each pixel).
+// ---------------------------------------------------------------------------------------------
+constexpr int kW8Rounds = 6;                      // DMA rounds of 32 patch pixels per plane
+constexpr int kW8PatchMax = kW8Rounds * 32;       // 192 patch pixels (10 x 18 for an 8 x 16 tile, 6 x 30 for 4 x 28)
+constexpr int kW8Plane = kW8PatchMax * 32;
+constexpr int kW8BufBytes = 8 * kW8Plane;         // 49 152 B
+constexpr int kW8LdsBytes = 2 * kW8BufBytes + 512;
+constexpr int kW8AgprFrags = 56;                  // fragments kept in accumulation registers
+
+__global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x kW8BufBytes | bias
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int H = p.H, W = p.W, TR = p.tr, TC = p.tc, PW = TC + 2;
+  const int nr = ((TR + 2) * PW + 31) >> 5;
+  const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR, tiles_f = tiles_x * tiles_y;
+  const int ntiles = p.N * tiles_f;
+  const int frame_bytes = H * W * 256;
+
+  // ---- the stationary operand: fragment s = tap * 8 + g of this wave's 32 output channels, k = 16 s + 8 half .. + 8
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w2), 0, 128 * 1152 * 2, 0x00020000);
+  u32x4 wr[72];
+#pragma unroll
+  for (int s = 0; s < 72; ++s)
+    wr[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, ((wave * 32 + l31) * 1152 + s * 16 + half * 8) * 2, 0, 0);
+#pragma unroll
+  for (int s = 0; s < kW8AgprFrags; ++s) asm volatile("" : "+a"(wr[s]));
+  float *bias_lds = reinterpret_cast<float *>(lds + 2 * kW8BufBytes);
+  if (tid < 128) bias_lds[tid] = p.bias2[tid];
+  const float floor_ = p.relu ? 0.f : -INFINITY;
+
+  // ---- loader: plane g holds bytes [32 g, 32 g + 32) of every patch pixel (halves swapped where (pixel >> 3) is odd);
+  // in round i this lane fills half (lane & 1) of patch pixel 32 i + (lane >> 1), in planes 2 wave and 2 wave + 1
+  const int hsel = (lane & 1) ^ ((lane >> 4) & 1);
+  unsigned dslot[kW8Rounds];                       // (byte offset of the pixel relative to the patch origin) >> 4 | patch column << 24
+#pragma unroll
+  for (int i = 0; i < kW8Rounds; ++i) {
+    const int pidx = 32 * i + (lane >> 1);
+    const int pr = pidx / PW, pc = pidx - pr * PW;
+    dslot[i] = (unsigned)((pr * W + pc) * 16) | ((unsigned)pc << 24);
+  }
+  auto issue_patch = [&](int t, int b) {
+    const int f = t / tiles_f, rem = t - f * tiles_f;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int x0 = tx * TC;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)f * frame_bytes), 0, frame_bytes, 0x00020000);
+    const int tbase = ((ty * TR - 1) * W + (x0 - 1)) * 256 + (4 * wave + hsel) * 16;
+    unsigned char *dst = lds + b * kW8BufBytes + 2 * wave * kW8Plane;
+#pragma unroll
+    for (int i = 0; i < kW8Rounds; ++i)
+      if (i < nr) {
+        const int xg = x0 - 1 + (int)(dslot[i] >> 24);
+        const unsigned off = (unsigned)tbase + ((dslot[i] & 0xFFFFFFu) << 4);
+        const unsigned o = (unsigned)xg < (unsigned)W ? off : kInvalid;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(dst + i * 1024), 16, (int)o, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(dst + kW8Plane + i * 1024), 16,
+                                                 (int)(o == kInvalid ? kInvalid : o + 32u), 0, 0, 0);
+      }
+  };
+
+  // ---- this lane's pixel in each of the four M-tiles (shared by all waves)
+  int prow[4], pcol[4], pp0[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int q = mt * 32 + l31;
+    const bool ok = q < TR * TC;
+    const int r = q / TC, c = q - r * TC;
+    prow[mt] = ok ? r : 0x4000;
+    pcol[mt] = c;
+    pp0[mt] = ok ? r * PW + c : 0;
+  }
+  const __amdgpu_buffer_rsrc_t rsrcYall = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * 256), 0x00020000);
+
+  // epilogue of a PAIR of M-tiles in ten pieces: per M-tile four (bias, ReLU, bf16 of group q) and one (lanes 0-31 take
+  // groups 0, 1, lanes 32-63 groups 2, 3: swap, two 16-byte stores into this wave's 64-byte slice of the pixel)
+  unsigned pk[4][2];
+  auto epi_piece = [&](const f32x16 (&a)[2], int k, const unsigned (&yoff)[2]) {
+    const int m = k / 5, q = k - m * 5;
+    if (q < 4) {
+      const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_lds + wave * 32 + 8 * q + 4 * half);
+      pk[q][0] = pack_bf16(fmaxf(a[m][4 * q] + b[0], floor_), fmaxf(a[m][4 * q + 1] + b[1], floor_));
+      pk[q][1] = pack_bf16(fmaxf(a[m][4 * q + 2] + b[2], floor_), fmaxf(a[m][4 * q + 3] + b[3], floor_));
+    } else {
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+          const auto r2 = __builtin_amdgcn_permlane32_swap(pk[qq][w2], pk[qq + 2][w2], false, false);
+          pk[qq][w2] = r2[0];
+          pk[qq + 2][w2] = r2[1];
+        }
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
+        __builtin_amdgcn_raw_buffer_store_b128(
+            o, rsrcYall, (int)(yoff[m] == kInvalid ? kInvalid : yoff[m] + (unsigned)(wave * 64 + (2 * half + qq) * 16)), 0, 0);
+      }
+    }
+  };
+  auto out_off = [&](int tt, int mt) -> unsigned {
+    const int f = tt / tiles_f, rem = tt - f * tiles_f;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int oy = ty * TR + prow[mt], ox = tx * TC + pcol[mt];
+    return (oy < H && ox < W) ? (unsigned)(((f * H + oy) * W + ox) * 256) : kInvalid;
+  };
+
+  // A pair of M-tiles (2 mp, 2 mp + 1): 72 steps (tap, g) of two pixel-fragment reads (two steps ahead) and two MFMAs
+  // with the same weight fragment; the pieces of the previous pair are spread over steps 3, 10, .., 66.
+  auto mpair = [&](const unsigned char *buf, int mp, f32x16 (&acc)[2], const f32x16 (&prev)[2], const unsigned (&prev_off)[2]) {
+    u32x4 px[4][2];
+    unsigned tb[2] = {0u, 0u};
+    auto rd = [&](int s) {
+      const int tap = s >> 3, g = s & 7, ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (g == 0) {
+          const int pp = pp0[2 * mp + m] + ky * PW + kx;
+          tb[m] = (unsigned)(pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4));
+        }
+        px[s & 3][m] = *reinterpret_cast<const u32x4 *>(buf + tb[m] + g * kW8Plane);
+      }
+    };
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    rd(0); rd(1); rd(2);
+    static_for<72>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s + 3 < 72) rd(s + 3);
+      if constexpr (s >= 3 && s < 70 && (s - 3) % 7 == 0) epi_piece(prev, (s - 3) / 7, prev_off);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr[s]), __builtin_bit_cast(bf16x8, px[s & 3][m]),
+                                                         acc[m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  f32x16 accA[2], accB[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accB[m][e] = 0.f;
+  unsigned offA[2], offB[2] = {kInvalid, kInvalid};                     // nothing to store before the first tile
+  int t = blockIdx.x, nb = 0;
+  if (t < ntiles) issue_patch(p.reverse ? ntiles - 1 - t : t, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  for (; t < ntiles; t += gridDim.x, nb ^= 1) {
+    __builtin_amdgcn_s_barrier();      // every wave's share of this patch has landed; nobody still reads the other buffer
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) issue_patch(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
+    const int tt = p.reverse ? ntiles - 1 - t : t;
+    const unsigned char *buf = lds + nb * kW8BufBytes;
+    mpair(buf, 0, accA, accB, offB);                                    // (B = M-tiles 2, 3 of the previous tile)
+    offA[0] = out_off(tt, 0); offA[1] = out_off(tt, 1);
+    mpair(buf, 1, accB, accA, offA);
+    offB[0] = out_off(tt, 2); offB[1] = out_off(tt, 3);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                    // the next patch is older than this iteration's eight stores
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) epi_piece(accB, k, offB);
+}
+
+bool conv3x3_ws128_valid(const ConvParams &p) {
+  int tr, tc;
+  return p.prec == kPrecBf16 && p.C == 128 && p.Cout == 128 && p.Kp == 1152 && p.stride == 1 && p.pad == 1 && p.Hi == p.Ho &&
+         p.Wi == p.Wo && !p.res && !p.x2 && p.T == 0 && p.kseg_len == 0 && (double)p.M * 256.0 < 2.0e9 &&
+         ws_tile_geometry(p.Hi, p.Wi, &tr, &tc, 128, kW8PatchMax);
+}
+
 bool conv3x3_ws_valid(const ConvParams &p) {
   int tr, tc;
   return p.prec == kPrecBf16 && p.C == 64 && p.Cout == 64 && p.Kp == 576 && p.stride == 1 && p.pad == 1 && p.Hi == p.Ho &&
@@ -1648,11 +1843,23 @@ static int ws_grid_setup() {
                               kWsLdsBytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kWsLdsBytes3All);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ws128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kW8LdsBytes);
   }
   return n_cu;
 }
 
 static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
+  if (conv3x3_ws128_valid(p)) {
+    WsParams q{};
+    q.x = p.x; q.w2 = p.w; q.bias2 = p.bias; q.y = p.y;
+    q.N = p.N; q.H = p.Hi; q.W = p.Wi; q.M = p.M; q.relu = p.relu; q.reverse = p.reverse;
+    ws_tile_geometry(q.H, q.W, &q.tr, &q.tc, 128, kW8PatchMax);
+    const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
+    const int n_cu = ws_grid_setup();
+    hipLaunchKernelGGL(conv3x3_ws128_kernel, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kW8LdsBytes, s, q);
+    return hipGetLastError();
+  }
   if (!conv3x3_ws_valid(p)) return hipErrorInvalidValue;
   WsParams q{};
   q.x = p.x; q.w2 = p.w; q.bias2 = p.bias; q.y = p.y;
