@@ -19,3 +19,5 @@ python3 tools/layer_times.py $G/${t}_bf16x3_stats/run_kernel_trace.csv 256 224 >
 [ -f $G/${t}_bench_default.json ] && tail -1 $G/${t}_bench_default.json > $P/${t}_bench_line.json
 [ -f $G/${t}_bench_c5.json ] && tail -1 $G/${t}_bench_c5.json > $P/${t}_bench_line_config5.json
 ls $P | grep ${t}_ | wc -l
+[ -f $G/${t}_tile_probe.txt ] && cp $G/${t}_tile_probe.txt $P/${t}_bf16_config5_tile_probe.txt
+[ -f $G/${t}_fused_probe_bf16.txt ] && cp $G/${t}_fused_probe_bf16.txt $P/${t}_bf16_config5_fused_probe.txt

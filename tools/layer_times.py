@@ -37,7 +37,8 @@ def main(path, frames=256, size=224):
             convs[-1]['Kernel_Name'] = convs[-1]['Kernel_Name'].replace('>', ' +reduce>', 1)
     byname = {r['name']: r for r in layer_table(size, size)}
     # Expected launch order, consumed against the trace: the stem; per block [downsample,] conv1, then either conv2 and
-    # conv3 (the latter fused with the downsample branch in a stage's first block) or ONE conv23_fused launch.
+    # conv3 (the latter fused with the downsample branch in a stage's first block) or ONE conv23_fused /
+    # conv3x3_ws_kernel<true> launch.
     def _dual(name):      # conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, PREC, DUAL, SEG> / conv_bf16_256_kernel<KS, SHIFT, RES, DUAL>
         if '<' not in name:
             return False
@@ -65,7 +66,7 @@ def main(path, frames=256, size=224):
             nxt = next(it, None)
             if nxt is None:
                 break
-            if 'conv23_fused' in nxt['Kernel_Name']:
+            if 'conv23_fused' in nxt['Kernel_Name'] or 'conv3x3_ws_kernel<true>' in nxt['Kernel_Name']:
                 rows.append((p + '.conv2+conv3', [p + '.conv2', p + '.conv3'], nxt))
                 continue
             rows.append((p + '.conv2', [p + '.conv2'], nxt))
@@ -79,7 +80,7 @@ def main(path, frames=256, size=224):
         tot += dur
         totf += fl
         kn = r['Kernel_Name'].split('<')[1].split('>')[0] if '<' in r['Kernel_Name'] else r['Kernel_Name'][:30]
-        if 'conv23_fused' in r['Kernel_Name'] or 'conv_bf16_256' in r['Kernel_Name']:
+        if any(k in r['Kernel_Name'] for k in ('conv23_fused', 'conv_bf16_256', 'conv3x3_ws')):
             kn = r['Kernel_Name'].split('tsm::')[1].split('(')[0]
         grid = int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))
         print(f"{nm:26s} {kn:44s} wgs={grid:6d} {dur:8.1f}us {fl / dur / 1e6:7.1f} TF/s  vgpr={r.get('VGPR_Count','?')}")

@@ -30,6 +30,7 @@ namespace tsm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // LDS row stride in floats: 32 data + 4 pad.  With ds_read_b128 (16-lane groups, 64 banks) the 16
@@ -1215,7 +1216,8 @@ constexpr int kWsLdsBytes = 2 * kWsBufBytes + 256;
 constexpr int kWsTableOff = kWsBufBytes + 256 + 1024 + 32768;      // FUSE3: one patch buffer, bias2, bias3, conv3's weights in fragment order
 constexpr int kWsRingOff = kWsTableOff + kWsRounds * 1024;         // ... the loader's per-thread offset table
 constexpr int kWsSlots = 4;                                        // residual ring: slots of 4 KB (one 32-channel tile of the wave's 64 pixels) per wave
-constexpr int kWsLdsBytes3All = kWsRingOff + 4 * kWsSlots * 4096;  // 155 904 B
+constexpr int kWsLaneOff = kWsRingOff + 4 * kWsSlots * 4096;       // ... six per-thread tile-invariant words (pixel positions)
+constexpr int kWsLdsBytes3All = kWsLaneOff + 6 * 1024;             // 162 048 B
 static_assert(kWsLdsBytes3All <= 160 * 1024, "LDS budget of the fused weight-stationary kernel");
 constexpr int kWsAgprFrags1 = 20;                // fragments of the second output-channel tile kept in accumulation registers
 
@@ -1521,13 +1523,17 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const WsParams p) {
     unsigned char *ring = lds + kWsRingOff + wave * (kWsSlots * 4096);
     // loader lanes of the ring: lane fills position (lane & 3) of pixel 16 j + (lane >> 2), j = 0..3
     const int rchunk = ((lane & 3) - (lane >> 4)) & 3;
-    int drc[4];                                                         // that pixel's tile row | column << 16 (row 0x4000: not in the tile)
+    // per-thread words kept in LDS (the registers are spent on weights): [0..3] the loader pixel's tile row | column << 16
+    // (row 0x4000: not in the tile), [4..5] the same for this lane's pixel of M-tile 0 / 1
+    int *lane_lds = reinterpret_cast<int *>(lds + kWsLaneOff) + tid;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int q = wave * 64 + 16 * j + (lane >> 2);
       const int r = q / TC, c = q - r * TC;
-      drc[j] = (q < TR * TC ? r : 0x4000) | (c << 16);
+      lane_lds[j * 256] = (q < TR * TC ? r : 0x4000) | (c << 16);
     }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) lane_lds[(4 + mt) * 256] = prow[mt] | (pcol[mt] << 16);
     unsigned rrd[2];                                                    // read offset of this lane's pixel of M-tile mt, group q = 0 (+ 16 ((q + s) & 3) - 16 s per q)
     const int rsw = (l31 >> 2) & 3;
 #pragma unroll
@@ -1543,12 +1549,14 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const WsParams p) {
       unsigned yo[2], ro[4];       // byte offset of the 256 channels of: this lane's pixel of M-tile mt / its loader pixel j (+ its chunk)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const int oy = ty * TR + prow[mt], ox = tx * TC + pcol[mt];
+        const int rc = lane_lds[(4 + mt) * 256];
+        const int oy = ty * TR + (rc & 0xFFFF), ox = tx * TC + (rc >> 16);
         yo[mt] = (oy < H && ox < W) ? (unsigned)((oy * W + ox) * 512) : kInvalid;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int oy = ty * TR + (drc[j] & 0xFFFF), ox = tx * TC + (drc[j] >> 16);
+        const int rc = lane_lds[j * 256];
+        const int oy = ty * TR + (rc & 0xFFFF), ox = tx * TC + (rc >> 16);
         ro[j] = (oy < H && ox < W) ? (unsigned)((oy * W + ox) * 512 + rchunk * 16) : kInvalid;
       }
       auto issue_res = [&](int it) {                                    // 4 vector-memory operations
@@ -1576,6 +1584,22 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const WsParams p) {
       }
       // ---- conv3: eight tiles of 32 output channels, both M-tiles per W3 fragment; the wait of tile `it` leaves exactly
       // the vector-memory operations younger than its ring fill in flight (ws_younger_than_fill)
+      // (software-pipelined: the eight MFMAs of tile it + 1 are issued before the epilogue of tile it and run under it)
+      f32x16 c3[2][2];
+      auto conv3_mfma = [&](int it, f32x16 (&c)[2]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) c[mt][e] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x8 wf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(w3_lds + (it * 4 + g) * 1024 + lane * 16));
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            c[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8, mid[mt][g]), c[mt], 0, 0, 0);
+        }
+      };
+      conv3_mfma(0, c3[0]);
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         wait_vmcnt(ws_younger_than_fill(it));
@@ -1591,18 +1615,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const WsParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the slot is free again
         if (it + kWsSlots < 8) issue_res(it + kWsSlots);
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 c3[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) c3[mt][e] = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const bf16x8 wf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(w3_lds + (it * 4 + g) * 1024 + lane * 16));
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-            c3[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, __builtin_bit_cast(bf16x8, mid[mt][g]), c3[mt], 0, 0, 0);
-        }
+        if (it + 1 < 8) conv3_mfma(it + 1, c3[(it + 1) & 1]);
+        f32x16 (&cc)[2] = c3[it & 1];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           // + bias3, + residual, ReLU, bf16; lanes 0-31 then take groups 0, 1 and lanes 32-63 groups 2, 3 of the pixel
@@ -1610,16 +1624,13 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const WsParams p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 b = *reinterpret_cast<const f32x4 *>(bias3_lds + it * 32 + 8 * q + 4 * half);
-            float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const unsigned w2 = rp[mt][q][j >> 1];
-              v[j] = c3[mt][4 * q + j] + b[j];
-              v[j] += __builtin_bit_cast(float, (j & 1) ? (w2 & 0xFFFF0000u) : (w2 << 16));
-              v[j] = fmaxf(v[j], 0.f);
+            for (int w2 = 0; w2 < 2; ++w2) {                // two channels at a time: packed fp32 adds (v_pk_add_f32)
+              const unsigned rw = rp[mt][q][w2];
+              f32x2 v = f32x2{cc[mt][4 * q + 2 * w2], cc[mt][4 * q + 2 * w2 + 1]} + f32x2{b[2 * w2], b[2 * w2 + 1]};
+              v += f32x2{__builtin_bit_cast(float, rw << 16), __builtin_bit_cast(float, rw & 0xFFFF0000u)};
+              pk[q][w2] = pack_bf16(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
             }
-            pk[q][0] = pack_bf16(v[0], v[1]);
-            pk[q][1] = pack_bf16(v[2], v[3]);
           }
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq)
@@ -1634,6 +1645,18 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const WsParams p) {
             const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
             __builtin_amdgcn_raw_buffer_store_b128(
                 o, rsrcY, (int)(yo[mt] == kInvalid ? kInvalid : yo[mt] + (unsigned)(it * 64 + (2 * half + qq) * 16)), 0, 0);
+          }
+        }
+        // schedule of this region: one W3 fragment read, then its two MFMAs, each followed by a share of the epilogue's
+        // vector ALU work (in program order the eight MFMAs would be issued back to back and stall the wave on the pipe)
+        if (it + 1 < 8) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // VALU
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
