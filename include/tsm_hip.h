@@ -147,8 +147,10 @@ int tsm_layer_times(tsm_engine *e, int32_t forward_index, float *ms_out, int32_t
 
 /* Conv tile code the engine's autotuner chose for each conv launch of an `n_clips` forward, in launch order (stem,
  * then per block [downsample,] conv1, conv2, conv3): 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x32 (one wave),
- * 5 = 128x128 on 8 waves, 0 = not tuned (heuristic); + 256 = split-K form of a segmented fp32 layer (one workgroup per
- * tile and K segment, combined in segment order).  The first tsm_forward with a new power-of-two bucket of n_clips
+ * 5 = 128x128 on 8 waves, 6 = 256x256 LDS-DMA kernel (bf16), 7 = weight-stationary 3x3 (bf16, 64 -> 64 / 128 -> 128
+ * channels), 0 = not tuned (heuristic); + 256 = split-K form of a segmented fp32 layer (one workgroup per tile and K
+ * segment, combined in segment order); + 1024 (on conv2's code) = the block runs conv2 + conv3 + residual as ONE launch
+ * (conv3's slot is then not used).  The first tsm_forward with a new power-of-two bucket of n_clips
  * times every valid code per layer once (results are bit-identical across codes); TSM_AUTOTUNE=0 in the environment
  * at tsm_create disables it.  Every TSM_* environment variable is read once, in tsm_create. */
 int tsm_conv_tiles(tsm_engine *e, int32_t n_clips, int32_t *tiles_out, int32_t cap, int32_t *n_out);
