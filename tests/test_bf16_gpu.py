@@ -219,3 +219,33 @@ def test_weight_stationary_3x3_equals_the_igemm_tiles_bitwise(hip_lib, monkeypat
     if n * hi * wi <= 70000:
         want = tsm_oracle.conv_bn_act(x, w, bn, 1, 1, relu, None)
         assert_close(_nchw(outs['ws']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='ws bf16')
+
+
+@pytest.mark.parametrize('cin,n,hi,wi,shiftT,relu', [
+    (256, 16, 64, 64, 16, True),   # layer1.1 / 1.2 conv1 at the config-5 size (one clip): 512 tiles, shift over 16 frames
+    (256, 32, 56, 56, 8, True),    # at 224^2, four clips: 784 tiles (3 per workgroup), tiles straddle frames (3136 rows per frame)
+    (64, 16, 64, 64, 16, True),    # layer1.0 conv1 (stem output, 64 channels): fold = 8
+    (64, 24, 23, 18, 8, False),    # ragged last tile, no ReLU
+    (256, 9, 7, 5, 3, True),       # frames smaller than a tile: a tile spans several frames of several clips
+    (256, 5, 20, 20, 0, True),     # no shift at all
+    (64, 700, 8, 8, 7, True),      # more tiles than workgroups, odd segment count
+])
+def test_weight_stationary_1x1_equals_the_igemm_tiles_bitwise(hip_lib, monkeypatch, cin, n, hi, wi, shiftT, relu):
+    """conv1x1_ws_kernel (layer1's conv1: W1 resident in registers, a whole 128-pixel tile by LDS-DMA one tile ahead, the
+    temporal shift as an address choice per 16-byte chunk, zeros at the clip's ends) against conv_igemm's bf16 tiles
+    through the per-op entry point -- same bits -- and against the fp32 oracle at the bf16 mode's tolerance."""
+    from workoutdetector_amd.engine import conv_bn_act_nhwc
+    g = torch.Generator().manual_seed(9300 + cin + n + hi)
+    x = torch.randn(n, cin, hi, wi, generator=g)
+    w = torch.randn(64, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    bn = _bn(64, g)
+    outs = {}
+    for tile in ('ws', '128x64', '64x64'):
+        monkeypatch.setenv('TSM_CONV_TILE', tile)
+        outs[tile] = conv_bn_act_nhwc(_nhwc(x).cuda(), w.cuda(), *[b.cuda() for b in bn], stride=1, relu=relu,
+                                      shift_segments=shiftT, fold_div=8, dtype='bf16').cpu()
+    assert torch.equal(outs['64x64'], outs['128x64'])
+    assert torch.equal(outs['ws'], outs['64x64'])
+    xin = tsm_oracle.temporal_shift(x, shiftT, 8) if shiftT else x
+    want = tsm_oracle.conv_bn_act(xin, w, bn, 1, 0, relu, None)
+    assert_close(_nchw(outs['ws']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='ws 1x1 bf16')

@@ -817,7 +817,7 @@ bool conv_tile_valid(const ConvParams &p, int tile) {
     case kTile256x256:   // (ks is checked at launch: the stem has C == 4 and never qualifies)
       return p.prec == kPrecBf16 && p.Cout % 256 == 0 && p.C % 64 == 0 && !(p.res && p.x2) &&
              (!p.x2 || (p.K1 % 64 == 0 && p.C2 % 64 == 0));
-    case kTileWs: return conv3x3_ws_valid(p) || conv3x3_ws128_valid(p);   // (pad == 1 singles out the 3x3 conv)
+    case kTileWs: return conv3x3_ws_valid(p) || conv3x3_ws128_valid(p) || conv1x1_ws_valid(p);   // (pad singles out 3x3 / 1x1)
     default: return false;
   }
 }
@@ -829,6 +829,7 @@ void conv_tile_dims(int tile, int *bm, int *bn) {
 
 static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s);
 static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s);
+static hipError_t launch_conv1x1_ws(const ConvParams &p, hipStream_t s);
 
 template <int KS, bool SHIFT, bool RES>
 static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
@@ -845,6 +846,7 @@ static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
   }
   if (p.tile == kTileWs) {
     if constexpr (KS == 3) return launch_conv3x3_ws(p, s);
+    else if constexpr (KS == 1 && !RES) return launch_conv1x1_ws(p, s);
     else return hipErrorInvalidValue;
   }
   if (p.kseg_len > 0 && !(bm == 32 && bn == 32)) {  // segmented accumulation exists on 64x64 / 32x32 tiles only
@@ -1848,6 +1850,148 @@ bool conv3x3_ws128_valid(const ConvParams &p) {
          ws_tile_geometry(p.Hi, p.Wi, &tr, &tc, 128, kW8PatchMax);
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv1x1_ws: Bottleneck.conv1 of layer1 in bf16 (1x1, CIN = 64 or 256 -> 64 channels, the temporal shift fused into
+// the loader).  These launches are pure HBM streams (2.7 GB in 0.58 ms with conv_igemm's register-staged K loop, which
+// waits for every K-step's loads: 4.6 TB/s); this form keeps W1 (32 / 8 fragments per wave) in registers and brings
+// a tile's 128 pixels x CIN channels in by LDS-DMA, one whole tile (64 KB) ahead of its use, so the memory system
+// always has a CU's next 64 KB in flight and nothing in the compute loop waits on it.  A tile = 128 consecutive rows of
+// the flattened N*H*W; LDS = two buffers of CIN / 16 planes (plane g = bytes [32 g, 32 g + 32) of every pixel, halves
+// swapped where (pixel >> 3) is odd).  The shift is an address choice per 16-byte chunk: channels < fold come from frame
+// t + 1, < 2 fold from t - 1 (an out-of-range offset = zeros at the clip's ends).  Wave w multiplies pixels 32 w .. + 31
+// (transposed MFMA: one pixel-fragment read feeds both output-channel tiles), k16 groups ascending = conv_igemm's
+// order: bit-identical.  Epilogue from registers as in conv3x3_ws_kernel.
+// ---------------------------------------------------------------------------------------------
+struct Ws1Params {
+  const void *x;       // [M, CIN] bf16
+  const void *w;       // [64][CIN] bf16
+  const float *bias;   // [64]
+  void *y;             // [M, 64] bf16
+  int M, HW, T, fold, relu, reverse;
+};
+
+template <int CIN>
+__global__ void __launch_bounds__(256, 1) conv1x1_ws_kernel(const Ws1Params p) {
+  constexpr int NG = CIN / 16;           // k16 groups = LDS planes
+  constexpr int PPW = NG / 4;            // planes filled per wave
+  constexpr int kPlane = 128 * 32;       // 128 pixels x 32 B
+  constexpr int kBuf = NG * kPlane;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x kBuf | bias
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ntiles = (p.M + 127) >> 7;
+
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, 64 * CIN * 2, 0x00020000);
+  u32x4 wr[2][NG];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      wr[nt][g] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, ((nt * 32 + l31) * CIN + g * 16 + half * 8) * 2, 0, 0);
+  float *bias_lds = reinterpret_cast<float *>(lds + 2 * kBuf);
+  if (tid < 64) bias_lds[tid] = p.bias[tid];
+  const float floor_ = p.relu ? 0.f : -INFINITY;
+
+  // loader: in round i (0..3) this lane fills half (lane & 1) of tile pixel 32 i + (lane >> 1), in planes PPW wave .. + PPW - 1
+  const int hsel = (lane & 1) ^ ((lane >> 4) & 1);
+  const int frame_bytes = p.HW * CIN * 2;
+  auto issue_tile = [&](int t, int b) {
+    const int m0 = t * 128;
+    // descriptor rebased one frame before the tile: every offset below is small and non-negative
+    const long base_row = (long)m0 - p.HW;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.x) + base_row * (long)(CIN * 2)), 0,
+        (int)((size_t)(128 + 2 * p.HW) * CIN * 2 > 0x7FFFFFF0u ? 0x7FFFFFF0u : (size_t)(128 + 2 * p.HW) * CIN * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pl = 32 * i + (lane >> 1);
+      const int m = m0 + pl;
+      const bool ok = m < p.M;
+      const int n = (ok ? m : m0) / p.HW;
+      const int tt = p.T > 0 ? n % p.T : 0;
+      const unsigned own = (unsigned)((pl + p.HW) * CIN * 2);           // this pixel's row, relative to the rebased origin
+#pragma unroll
+      for (int k = 0; k < PPW; ++k) {
+        const int g = PPW * wave + k;
+        const int c0 = (2 * g + hsel) * 8;                              // first channel of this lane's 16-byte chunk
+        unsigned off = own;
+        bool valid = ok;
+        if (p.T > 0 && c0 < p.fold) { off = own + (unsigned)frame_bytes; valid = ok && tt < p.T - 1; }
+        else if (p.T > 0 && c0 < 2 * p.fold) { off = own - (unsigned)frame_bytes; valid = ok && tt > 0; }
+        // (the first tile's "frame before" lies before the tensor: only ever addressed with valid == false)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(lds + b * kBuf + g * kPlane + i * 1024), 16,
+                                                 (int)(valid ? off + (unsigned)(c0 * 2) : kInvalid), 0, 0, 0);
+      }
+    }
+  };
+
+  const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * 128), 0x00020000);
+  const int pp = wave * 32 + l31;                                        // this lane's pixel of the tile
+  const unsigned rd = (unsigned)(pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4));
+
+  int t = blockIdx.x, nb = 0;
+  if (t < ntiles) issue_tile(p.reverse ? ntiles - 1 - t : t, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  for (; t < ntiles; t += gridDim.x, nb ^= 1) {
+    __builtin_amdgcn_s_barrier();      // this tile has landed (every wave waited for its share); the other buffer is free
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) issue_tile(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
+    const int tt = p.reverse ? ntiles - 1 - t : t;
+    const unsigned char *buf = lds + nb * kBuf;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const u32x4 px = *reinterpret_cast<const u32x4 *>(buf + rd + g * kPlane);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr[nt][g]), __builtin_bit_cast(bf16x8, px),
+                                                          acc[nt], 0, 0, 0);
+    }
+    // epilogue: lane = pixel, acc[nt][4 q + j] = channel nt * 32 + 8 q + 4 half + j; lanes 0-31 store groups 0, 1 and
+    // lanes 32-63 groups 2, 3 of the pixel (v_permlane32_swap), 16 bytes each
+    const int m = tt * 128 + pp;
+    const unsigned yoff = m < p.M ? (unsigned)m * 128u : kInvalid;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      unsigned pk[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_lds + nt * 32 + 8 * q + 4 * half);
+        pk[q][0] = pack_bf16(fmaxf(acc[nt][4 * q] + b[0], floor_), fmaxf(acc[nt][4 * q + 1] + b[1], floor_));
+        pk[q][1] = pack_bf16(fmaxf(acc[nt][4 * q + 2] + b[2], floor_), fmaxf(acc[nt][4 * q + 3] + b[3], floor_));
+      }
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+          const auto r2 = __builtin_amdgcn_permlane32_swap(pk[qq][w2], pk[qq + 2][w2], false, false);
+          pk[qq][w2] = r2[0];
+          pk[qq + 2][w2] = r2[1];
+        }
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(yoff == kInvalid ? kInvalid : yoff + (unsigned)(nt * 64 + (2 * half + qq) * 16)),
+                                               0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the next tile is older than this tile's four stores
+  }
+}
+
+bool conv1x1_ws_valid(const ConvParams &p) {
+  return p.prec == kPrecBf16 && (p.C == 64 || p.C == 256) && p.Cout == 64 && p.Kp == p.C && p.stride == 1 && p.pad == 0 &&
+         p.Hi == p.Ho && p.Wi == p.Wo && !p.res && !p.x2 && p.kseg_len == 0 && (double)p.M * 128.0 < 2.0e9 &&
+         (p.T == 0 || (p.N % p.T == 0 && p.fold % 8 == 0 && 2 * p.fold <= p.C)) &&
+         (double)(128 + 2.0 * p.Hi * p.Wi) * p.C * 2.0 < 2.0e9;
+}
+
 bool conv3x3_ws_valid(const ConvParams &p) {
   int tr, tc;
   return p.prec == kPrecBf16 && p.C == 64 && p.Cout == 64 && p.Kp == 576 && p.stride == 1 && p.pad == 1 && p.Hi == p.Ho &&
@@ -1868,6 +2012,8 @@ static int ws_grid_setup() {
                               kWsLdsBytes3All);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ws128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kW8LdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_ws_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              2 * 16 * 4096 + 256);
   }
   return n_cu;
 }
@@ -1891,6 +2037,19 @@ static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
   const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
   const int n_cu = ws_grid_setup();
   hipLaunchKernelGGL(conv3x3_ws_kernel<false>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kWsLdsBytes, s, q);
+  return hipGetLastError();
+}
+
+static hipError_t launch_conv1x1_ws(const ConvParams &p, hipStream_t s) {
+  if (!conv1x1_ws_valid(p)) return hipErrorInvalidValue;
+  Ws1Params q{};
+  q.x = p.x; q.w = p.w; q.bias = p.bias; q.y = p.y;
+  q.M = p.M; q.HW = p.Hi * p.Wi; q.T = p.T; q.fold = p.fold; q.relu = p.relu; q.reverse = p.reverse;
+  const int n_cu = ws_grid_setup();
+  const int ntiles = (p.M + 127) / 128;
+  const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);
+  if (p.C == 256) hipLaunchKernelGGL(conv1x1_ws_kernel<256>, dim3(grid), dim3(256), 2 * 16 * 4096 + 256, s, q);
+  else hipLaunchKernelGGL(conv1x1_ws_kernel<64>, dim3(grid), dim3(256), 2 * 4 * 4096 + 256, s, q);
   return hipGetLastError();
 }
 
