@@ -249,3 +249,52 @@ def test_weight_stationary_1x1_equals_the_igemm_tiles_bitwise(hip_lib, monkeypat
     xin = tsm_oracle.temporal_shift(x, shiftT, 8) if shiftT else x
     want = tsm_oracle.conv_bn_act(xin, w, bn, 1, 0, relu, None)
     assert_close(_nchw(outs['ws']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='ws 1x1 bf16')
+
+
+@pytest.mark.parametrize('cin,cout,n,hi,wi,shiftT,relu', [
+    (256, 128, 16, 64, 64, 16, True),   # layer2.0 conv1 at the config-5 size (one clip)
+    (512, 128, 16, 32, 32, 16, True),   # layer2.x conv1: 64-pixel tiles
+    (512, 256, 16, 32, 32, 16, True),   # layer3.0 conv1: 64 weight fragments per wave (accumulation registers)
+    (256, 128, 24, 23, 18, 8, False),   # ragged last tile, no ReLU
+    (512, 128, 9, 7, 5, 3, True),       # frames smaller than a tile
+    (512, 256, 5, 20, 20, 0, True),     # no shift
+    (256, 128, 700, 4, 4, 7, True),     # more tiles than workgroups, odd segment count
+])
+def test_weight_stationary_1x1_wide_equals_the_igemm_tiles_bitwise(hip_lib, monkeypatch, cin, cout, n, hi, wi, shiftT, relu):
+    """conv1x1_wsn_kernel (output channels split over the waves, whole pixel tiles by LDS-DMA one tile ahead, fused temporal
+    shift) against conv_igemm's bf16 tiles through the per-op entry point -- same bits -- and against the fp32 oracle."""
+    from workoutdetector_amd.engine import conv_bn_act_nhwc
+    g = torch.Generator().manual_seed(9500 + cin + cout + n + hi)
+    x = torch.randn(n, cin, hi, wi, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    bn = _bn(cout, g)
+    outs = {}
+    for tile in ('ws', '128x128', '64x64'):
+        monkeypatch.setenv('TSM_CONV_TILE', tile)
+        outs[tile] = conv_bn_act_nhwc(_nhwc(x).cuda(), w.cuda(), *[b.cuda() for b in bn], stride=1, relu=relu,
+                                      shift_segments=shiftT, fold_div=8, dtype='bf16').cpu()
+    assert torch.equal(outs['64x64'], outs['128x128'])
+    assert torch.equal(outs['ws'], outs['64x64'])
+    xin = tsm_oracle.temporal_shift(x, shiftT, 8) if shiftT else x
+    want = tsm_oracle.conv_bn_act(xin, w, bn, 1, 0, relu, None)
+    assert_close(_nchw(outs['ws']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='wsn 1x1 bf16')
+
+
+@pytest.mark.parametrize('h,w,b', [(256, 256, 2), (224, 224, 2), (90, 70, 3)])
+def test_weight_stationary_kernels_forced_everywhere_equal_the_igemm_engine_bitwise(hip_lib, sd0, monkeypatch, h, w, b):
+    """An engine with TSM_CONV_TILE=ws (every layer that has a weight-stationary form runs it: conv1 / conv2 of layer1,
+    conv3 + downsample of layer1.0 as the K-concatenated GEMM, conv1 / conv2 of layer2, conv1 of layer3.0) against one
+    forced onto the 64x64 tile: block outputs and logits bit for bit."""
+    from workoutdetector_amd.engine import TsmEngine
+    x = make_input(300 + h, b, 8, h, w)
+    got = {}
+    for tile in ('ws', '64x64'):
+        monkeypatch.setenv('TSM_AUTOTUNE', '0')
+        monkeypatch.setenv('TSM_CONV_TILE', tile)
+        monkeypatch.setenv('TSM_FUSE_CONV23', '0')
+        eng = TsmEngine(height=h, width=w, max_clips=b, state_dict=sd0, dtype='bf16')
+        got[tile] = [eng.forward_tap(x, s) for s in ('layer1.0', 'layer1.2', 'layer2.0', 'layer2.3', 'layer3.0')] + \
+                    [eng.run(None, {'input': x})[0]]
+        eng.close()
+    for a, c in zip(got['ws'], got['64x64']):
+        assert np.array_equal(a, c)

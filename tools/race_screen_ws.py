@@ -1,4 +1,4 @@
-"""Race screen for the weight-stationary kernels (conv3x3_ws_kernel<false|true>, conv3x3_ws128_kernel, conv1x1_ws_kernel: hand-placed counted
+"""Race screen for the weight-stationary kernels (conv3x3_ws_kernel<false|true>, conv3x3_ws128_kernel, conv1x1_ws[n]_kernel: hand-placed counted
 vmcnt waits, LDS-DMA into buffers that are re-used, one barrier per tile, a wave-private residual ring): every case is
 run REPS times back to back and every result is compared bit for bit with the igemm path.  A schedule that reads a
 staged patch / ring slot too early passes most runs and fails some; this looks for the some.
@@ -34,13 +34,15 @@ for ch, n, h, w in [(64, 64, 64, 64), (64, 200, 64, 64), (64, 96, 56, 56), (64, 
         fails += int(not torch.equal(got, ref))
     bad += fails
     print(f'per-op  ch={ch} n={n} {h}x{w}: {fails}/{REPS} runs differ from the 64x64 tile')
-# conv1x1_ws_kernel (layer1's conv1 with the fused temporal shift)
-for cin, n, h, w, T in [(256, 64, 64, 64, 16), (256, 96, 56, 56, 8), (64, 64, 64, 64, 16), (256, 27, 7, 5, 3), (64, 700, 8, 8, 7)]:
-    g = torch.Generator().manual_seed(n + cin + 1)
+# conv1x1_ws_kernel / conv1x1_wsn_kernel (conv1 of layer1 / layer2 / layer3.0 with the fused temporal shift)
+for cin, cout, n, h, w, T in [(256, 64, 64, 64, 64, 16), (256, 64, 96, 56, 56, 8), (64, 64, 64, 64, 64, 16), (256, 64, 27, 7, 5, 3),
+                               (64, 64, 700, 8, 8, 7), (256, 128, 64, 64, 64, 16), (512, 128, 96, 32, 32, 16), (512, 256, 96, 32, 32, 8),
+                               (512, 128, 27, 7, 5, 3)]:
+    g = torch.Generator().manual_seed(n + cin + cout + 1)
     x = torch.randn(n, h, w, cin, generator=g).cuda()
-    wt = (torch.randn(64, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).cuda()
-    bn = [torch.rand(64, generator=g).cuda() + 0.5, torch.randn(64, generator=g).cuda() * 0.1,
-          torch.randn(64, generator=g).cuda() * 0.1, torch.rand(64, generator=g).cuda() + 0.5]
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).cuda()
+    bn = [torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda() * 0.1,
+          torch.randn(cout, generator=g).cuda() * 0.1, torch.rand(cout, generator=g).cuda() + 0.5]
     os.environ['TSM_CONV_TILE'] = '64x64'
     ref = conv_bn_act_nhwc(x, wt, *bn, stride=1, relu=True, shift_segments=T, dtype='bf16')
     os.environ['TSM_CONV_TILE'] = 'ws'
@@ -49,7 +51,7 @@ for cin, n, h, w, T in [(256, 64, 64, 64, 16), (256, 96, 56, 56, 8), (64, 64, 64
         got = conv_bn_act_nhwc(x, wt, *bn, stride=1, relu=True, shift_segments=T, dtype='bf16')
         fails += int(not torch.equal(got, ref))
     bad += fails
-    print(f'per-op  1x1 cin={cin} n={n} {h}x{w} T={T}: {fails}/{REPS} runs differ from the 64x64 tile')
+    print(f'per-op  1x1 {cin}->{cout} n={n} {h}x{w} T={T}: {fails}/{REPS} runs differ from the 64x64 tile')
 os.environ.pop('TSM_CONV_TILE', None)
 sd = make_state_dict(0, 12)
 for b, t, s in [(4, 8, 224), (8, 16, 256), (3, 8, 96), (2, 8, 90)]:

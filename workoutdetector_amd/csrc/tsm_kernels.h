@@ -60,6 +60,7 @@ bool conv_tile_valid(const ConvParams &p, int tile);
 // Do the weight-stationary 3x3 kernels (kTileWs: 64 -> 64 channels, or 128 -> 128) apply to this problem?
 bool conv3x3_ws_valid(const ConvParams &p);
 bool conv3x3_ws128_valid(const ConvParams &p);
+bool conv1x1_wsn_valid(const ConvParams &p);  // 1x1 to 128 / 256 channels (conv1 of layer2 / layer3.0, conv3 + downsample of layer1.0)
 bool conv1x1_ws_valid(const ConvParams &p);   // 1x1, 64 / 256 -> 64 channels, optional fused temporal shift (layer1's conv1)
 
 // ks in {1, 3, 7}.  Returns hipSuccess or the launch error.

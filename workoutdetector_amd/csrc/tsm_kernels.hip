@@ -817,7 +817,7 @@ bool conv_tile_valid(const ConvParams &p, int tile) {
     case kTile256x256:   // (ks is checked at launch: the stem has C == 4 and never qualifies)
       return p.prec == kPrecBf16 && p.Cout % 256 == 0 && p.C % 64 == 0 && !(p.res && p.x2) &&
              (!p.x2 || (p.K1 % 64 == 0 && p.C2 % 64 == 0));
-    case kTileWs: return conv3x3_ws_valid(p) || conv3x3_ws128_valid(p) || conv1x1_ws_valid(p);   // (pad singles out 3x3 / 1x1)
+    case kTileWs: return conv3x3_ws_valid(p) || conv3x3_ws128_valid(p) || conv1x1_ws_valid(p) || conv1x1_wsn_valid(p);   // (pad singles out 3x3 / 1x1)
     default: return false;
   }
 }
@@ -830,6 +830,7 @@ void conv_tile_dims(int tile, int *bm, int *bn) {
 static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s);
 static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s);
 static hipError_t launch_conv1x1_ws(const ConvParams &p, hipStream_t s);
+static hipError_t launch_conv1x1_wsn(const ConvParams &p, hipStream_t s);
 
 template <int KS, bool SHIFT, bool RES>
 static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
@@ -846,7 +847,7 @@ static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
   }
   if (p.tile == kTileWs) {
     if constexpr (KS == 3) return launch_conv3x3_ws(p, s);
-    else if constexpr (KS == 1 && !RES) return launch_conv1x1_ws(p, s);
+    else if constexpr (KS == 1 && !RES) return conv1x1_ws_valid(p) ? launch_conv1x1_ws(p, s) : launch_conv1x1_wsn(p, s);
     else return hipErrorInvalidValue;
   }
   if (p.kseg_len > 0 && !(bm == 32 && bn == 32)) {  // segmented accumulation exists on 64x64 / 32x32 tiles only
@@ -1992,6 +1993,174 @@ bool conv1x1_ws_valid(const ConvParams &p) {
          (double)(128 + 2.0 * p.Hi * p.Wi) * p.C * 2.0 < 2.0e9;
 }
 
+// conv1x1_wsn: the same streaming form for 128 / 256 output channels (conv1 of layer2 and of layer3.0, conv3 + downsample of
+// layer1.0 as one GEMM over [conv3 input | block input]): the OUTPUT CHANNELS are split over the four waves (wave w keeps
+// the fragments of channels COUT / 4 * w ..) and every wave multiplies all PX pixels of the tile.  PX = 128 (CIN <= 256)
+// or 64 (CIN = 512): a tile buffer is 64 KB either way.  DUAL: chunks past K1 come from the second source (its own
+// stride and frame size); SHIFT sources as in conv1x1_ws.
+struct WsnParams {
+  const void *x, *x2, *w;
+  const float *bias;
+  void *y;
+  int M, HW, Wo, T, fold, relu, reverse;
+  int K1;                    // channels of the first source (= CIN unless DUAL)
+  int Hi2, Wi2, stride2;     // DUAL: second source [N, Hi2, Wi2, CIN - K1]
+};
+
+template <int CIN, int COUT, bool DUAL>
+__global__ void __launch_bounds__(256, 1) conv1x1_wsn_kernel(const WsnParams p) {
+  constexpr int PX = CIN <= 256 ? 128 : 64;
+  constexpr int MT = PX / 32;
+  constexpr int NG = CIN / 16;
+  constexpr int NTW = COUT / 128;        // output-channel tiles per wave
+  constexpr int PPW = NG / 4;            // planes filled per wave
+  constexpr int kPlane = PX * 32;
+  constexpr int kBuf = NG * kPlane;      // 64 KB
+  constexpr int kAgpr = NTW * NG > 48 ? NTW * NG - 24 : 0;   // fragments pinned to accumulation registers (the 256-register form)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x kBuf | bias
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int ntiles = (p.M + PX - 1) / PX;
+
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, COUT * CIN * 2, 0x00020000);
+  u32x4 wr[NTW][NG];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      wr[nt][g] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, (((wave * NTW + nt) * 32 + l31) * CIN + g * 16 + half * 8) * 2, 0, 0);
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (nt * NG + g < kAgpr) asm volatile("" : "+a"(wr[nt][g]));
+  float *bias_lds = reinterpret_cast<float *>(lds + 2 * kBuf);
+  if (tid < COUT) bias_lds[tid] = p.bias[tid];
+  const float floor_ = p.relu ? 0.f : -INFINITY;
+
+  const int hsel = (lane & 1) ^ ((lane >> 4) & 1);
+  const int C1 = DUAL ? p.K1 : CIN, C2 = CIN - C1;
+  const int frame_bytes = p.HW * C1 * 2;
+  const int frame2_bytes = DUAL ? p.Hi2 * p.Wi2 * C2 * 2 : 0;
+  auto issue_tile = [&](int t, int b) {
+    const int m0 = t * PX;
+    const long base_row = (long)m0 - p.HW;
+    const size_t span = (size_t)(PX + 2 * p.HW) * C1 * 2;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.x) + base_row * (long)(C1 * 2)), 0,
+        (int)(span > 0x7FFFFFF0u ? 0x7FFFFFF0u : span), 0x00020000);
+    const int n0 = m0 / p.HW;                                           // first frame of the tile
+    const __amdgpu_buffer_rsrc_t rsrcX2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(DUAL ? p.x2 : p.x) + (size_t)n0 * frame2_bytes), 0,
+        DUAL ? (int)((size_t)(PX / p.HW + 2) * frame2_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : (size_t)(PX / p.HW + 2) * frame2_bytes) : 0,
+        0x00020000);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int pl = 32 * i + (lane >> 1);
+      const int m = m0 + pl;
+      const bool ok = m < p.M;
+      const int n = (ok ? m : m0) / p.HW;
+      const int tt = p.T > 0 ? n % p.T : 0;
+      const unsigned own = (unsigned)((pl + p.HW) * C1 * 2);
+      unsigned own2 = 0;
+      if (DUAL) {
+        const int rem = (ok ? m : m0) - n * p.HW;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        own2 = (unsigned)((n - n0) * frame2_bytes + ((oy * p.stride2) * p.Wi2 + ox * p.stride2) * C2 * 2);
+      }
+#pragma unroll
+      for (int k = 0; k < PPW; ++k) {
+        const int g = PPW * wave + k;
+        const int c0 = (2 * g + hsel) * 8;
+        lds_void *dst = (lds_void *)(lds + b * kBuf + g * kPlane + i * 1024);
+        if (DUAL && c0 >= C1) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX2, dst, 16, (int)(ok ? own2 + (unsigned)((c0 - C1) * 2) : kInvalid), 0, 0, 0);
+        } else {
+          unsigned off = own;
+          bool valid = ok;
+          if (p.T > 0 && c0 < p.fold) { off = own + (unsigned)frame_bytes; valid = ok && tt < p.T - 1; }
+          else if (p.T > 0 && c0 < 2 * p.fold) { off = own - (unsigned)frame_bytes; valid = ok && tt > 0; }
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, dst, 16, (int)(valid ? off + (unsigned)(c0 * 2) : kInvalid), 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  const size_t ybytes = (size_t)p.M * COUT * 2;
+  int t = blockIdx.x, nb = 0;
+  if (t < ntiles) issue_tile(p.reverse ? ntiles - 1 - t : t, 0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  for (; t < ntiles; t += gridDim.x, nb ^= 1) {
+    __builtin_amdgcn_s_barrier();
+    const int tn = t + gridDim.x;
+    if (tn < ntiles) issue_tile(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
+    const int tt = p.reverse ? ntiles - 1 - t : t;
+    const unsigned char *buf = lds + nb * kBuf;
+    // output window of the tile (rebased: 32-bit offsets whatever M * COUT is)
+    const size_t y0 = (size_t)tt * PX * COUT * 2;
+    const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(p.y) + y0, 0, (int)(ybytes - y0 > (size_t)PX * COUT * 2 ? (size_t)PX * COUT * 2 : ybytes - y0), 0x00020000);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int pp = mt * 32 + l31;
+      const unsigned rd = (unsigned)(pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4));
+      f32x16 acc[NTW];
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const u32x4 px = *reinterpret_cast<const u32x4 *>(buf + rd + g * kPlane);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr[nt][g]), __builtin_bit_cast(bf16x8, px),
+                                                            acc[nt], 0, 0, 0);
+      }
+      const unsigned yoff = (unsigned)(pp * COUT * 2);                   // (rows past M fall outside the rebased window)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int ch0 = (wave * NTW + nt) * 32;
+        unsigned pk[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_lds + ch0 + 8 * q + 4 * half);
+          pk[q][0] = pack_bf16(fmaxf(acc[nt][4 * q] + b[0], floor_), fmaxf(acc[nt][4 * q + 1] + b[1], floor_));
+          pk[q][1] = pack_bf16(fmaxf(acc[nt][4 * q + 2] + b[2], floor_), fmaxf(acc[nt][4 * q + 3] + b[3], floor_));
+        }
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+          for (int w2 = 0; w2 < 2; ++w2) {
+            const auto r2 = __builtin_amdgcn_permlane32_swap(pk[qq][w2], pk[qq + 2][w2], false, false);
+            pk[qq][w2] = r2[0];
+            pk[qq + 2][w2] = r2[1];
+          }
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
+          __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(yoff + (unsigned)(ch0 * 2 + (2 * half + qq) * 16)), 0, 0);
+        }
+      }
+    }
+    wait_vmcnt(MT * NTW * 2);   // the next tile is older than this tile's stores
+  }
+}
+
+bool conv1x1_wsn_valid(const ConvParams &p) {
+  if (p.prec != kPrecBf16 || p.stride != 1 || p.pad != 0 || p.Hi != p.Ho || p.Wi != p.Wo || p.res || p.kseg_len != 0) return false;
+  if ((double)(128 + 2.0 * p.Hi * p.Wi) * p.C * 2.0 >= 2.0e9) return false;
+  if (p.x2) {   // conv3 + downsample of layer1.0: 64 + 64 -> 256
+    return p.T == 0 && p.C == 64 && p.C2 == 64 && p.K1 == 64 && p.Kp == 128 && p.Cout == 256 &&
+           (double)(128.0 / (p.Hi * p.Wi) + 2.0) * p.Hi2 * p.Wi2 * p.C2 * 2.0 < 2.0e9;
+  }
+  if (p.Kp != p.C) return false;
+  if (p.T > 0 && (p.N % p.T != 0 || p.fold % 8 != 0 || 2 * p.fold > p.C)) return false;
+  return (p.C == 256 && p.Cout == 128) || (p.C == 512 && p.Cout == 128) || (p.C == 512 && p.Cout == 256);
+}
+
 bool conv3x3_ws_valid(const ConvParams &p) {
   int tr, tc;
   return p.prec == kPrecBf16 && p.C == 64 && p.Cout == 64 && p.Kp == 576 && p.stride == 1 && p.pad == 1 && p.Hi == p.Ho &&
@@ -2014,6 +2183,10 @@ static int ws_grid_setup() {
                               kW8LdsBytes);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_ws_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               2 * 16 * 4096 + 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<128, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536 + 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<256, 128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536 + 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<512, 128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536 + 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<512, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536 + 1024);
   }
   return n_cu;
 }
@@ -2050,6 +2223,24 @@ static hipError_t launch_conv1x1_ws(const ConvParams &p, hipStream_t s) {
   const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);
   if (p.C == 256) hipLaunchKernelGGL(conv1x1_ws_kernel<256>, dim3(grid), dim3(256), 2 * 16 * 4096 + 256, s, q);
   else hipLaunchKernelGGL(conv1x1_ws_kernel<64>, dim3(grid), dim3(256), 2 * 4 * 4096 + 256, s, q);
+  return hipGetLastError();
+}
+
+static hipError_t launch_conv1x1_wsn(const ConvParams &p, hipStream_t s) {
+  if (!conv1x1_wsn_valid(p)) return hipErrorInvalidValue;
+  WsnParams q{};
+  q.x = p.x; q.x2 = p.x2; q.w = p.w; q.bias = p.bias; q.y = p.y;
+  q.M = p.M; q.HW = p.Hi * p.Wi; q.Wo = p.Wo; q.T = p.T; q.fold = p.fold; q.relu = p.relu; q.reverse = p.reverse;
+  q.K1 = p.x2 ? p.K1 : p.C; q.Hi2 = p.Hi2; q.Wi2 = p.Wi2; q.stride2 = p.stride2;
+  const int n_cu = ws_grid_setup();
+  const int px = p.Kp <= 256 ? 128 : 64;
+  const int ntiles = (p.M + px - 1) / px;
+  const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(256);
+  constexpr size_t kLds = 2 * 65536 + 1024;
+  if (p.x2) hipLaunchKernelGGL((conv1x1_wsn_kernel<128, 256, true>), grid, block, kLds, s, q);
+  else if (p.C == 256) hipLaunchKernelGGL((conv1x1_wsn_kernel<256, 128, false>), grid, block, kLds, s, q);
+  else if (p.Cout == 128) hipLaunchKernelGGL((conv1x1_wsn_kernel<512, 128, false>), grid, block, kLds, s, q);
+  else hipLaunchKernelGGL((conv1x1_wsn_kernel<512, 256, false>), grid, block, kLds, s, q);
   return hipGetLastError();
 }
 
