@@ -2797,17 +2797,20 @@ constexpr int kPoolCR = 2 * kPoolPH + 1, kPoolCC = 2 * kPoolPW + 1;  // conv til
 constexpr int kPoolPR = 2 * kPoolCR + 5, kPoolPC = kPoolCC + 3;      // input patch 35 rows x 20 pixel pairs
 
 template <bool X3>
-__global__ void __launch_bounds__(512) stem_pool_kernel(const float *__restrict__ x, const float *__restrict__ w,
+// (bf16: 77 760 B of LDS and <= 128 registers, so that TWO workgroups share a CU and overlap each other's phases)
+__global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ bias, float *__restrict__ y, int n,
                                                         int hi, int wi, int ho, int wo, int hp, int wp, int kp, int relu) {
   constexpr int NT = 512;
   constexpr int GB = X3 ? 32 : 16;
-  constexpr int WROW = X3 ? 1040 : 528;
+  constexpr int WROW = X3 ? 1040 : 464;   // weight row stride: data + padding, conflict-free ds_read_b128 over 16 rows
+  constexpr int CSB = X3 ? 256 * 68 * 4 : 256 * 72 * 2;   // the conv tile: [256][68] fp32, or (bf16) [256][72] bf16 bit patterns
   constexpr int OPX = X3 ? 256 : 128;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * WROW + kPoolPR * kPoolPC * GB + 256 * 68 * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * WROW + kPoolPR * kPoolPC * GB + CSB];
   unsigned char *Ws = smem;
   unsigned char *Ps = smem + 64 * WROW;
-  float *Cs = reinterpret_cast<float *>(smem + 64 * WROW + kPoolPR * kPoolPC * GB);  // [256][68] fp32: the conv tile
+  float *Cs = reinterpret_cast<float *>(smem + 64 * WROW + kPoolPR * kPoolPC * GB);  // X3: [256][68] fp32
+  unsigned short *Cs16 = reinterpret_cast<unsigned short *>(Cs);                     // bf16: [256][72] bf16
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wpairs = (wi + 1) >> 1;
@@ -2906,10 +2909,10 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const float *__restrict_
           unsigned hw, lw;
           split_pair(v, 0.f, &hw, &lw);
           v = __builtin_bit_cast(float, hw << 16) + __builtin_bit_cast(float, lw << 16);
-        } else {
-          v = __builtin_bit_cast(float, pack_bf16(v, 0.f) << 16);
+          Cs[row * 68 + j * 32 + l31] = inside ? v : -INFINITY;
+        } else {   // the value the format stores, as its 16 bits (0xFF80 = -inf)
+          Cs16[row * 72 + j * 32 + l31] = inside ? (unsigned short)(pack_bf16(v, 0.f) & 0xFFFFu) : (unsigned short)0xFF80u;
         }
-        Cs[row * 68 + j * 32 + l31] = inside ? v : -INFINITY;
       }
     }
     __syncthreads();
@@ -2923,8 +2926,18 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const float *__restrict_
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const float *src = Cs + ((2 * pyl + ky) * kPoolCC + 2 * pxl + kx) * 68 + cg * 8;
-          const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+          f32x4 v0, v1;
+          if constexpr (X3) {
+            const float *src = Cs + ((2 * pyl + ky) * kPoolCC + 2 * pxl + kx) * 68 + cg * 8;
+            v0 = *reinterpret_cast<const f32x4 *>(src);
+            v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+          } else {
+            const u32x4 pkd = *reinterpret_cast<const u32x4 *>(Cs16 + ((2 * pyl + ky) * kPoolCC + 2 * pxl + kx) * 72 + cg * 8);
+            v0 = f32x4{__builtin_bit_cast(float, pkd[0] << 16), __builtin_bit_cast(float, pkd[0] & 0xFFFF0000u),
+                       __builtin_bit_cast(float, pkd[1] << 16), __builtin_bit_cast(float, pkd[1] & 0xFFFF0000u)};
+            v1 = f32x4{__builtin_bit_cast(float, pkd[2] << 16), __builtin_bit_cast(float, pkd[2] & 0xFFFF0000u),
+                       __builtin_bit_cast(float, pkd[3] << 16), __builtin_bit_cast(float, pkd[3] & 0xFFFF0000u)};
+          }
           m[0] = fmaxf(m[0], v0[0]); m[1] = fmaxf(m[1], v0[1]); m[2] = fmaxf(m[2], v0[2]); m[3] = fmaxf(m[3], v0[3]);
           m[4] = fmaxf(m[4], v1[0]); m[5] = fmaxf(m[5], v1[1]); m[6] = fmaxf(m[6], v1[2]); m[7] = fmaxf(m[7], v1[3]);
         }
@@ -3078,7 +3091,8 @@ hipError_t launch_stem_pool(const float *x, const float *w, const float *bias, f
   if (prec != kPrecBf16 && prec != kPrecBf16x3 && prec != kPrecF32) return hipErrorInvalidValue;
   if ((double)hi * wi * 16.0 > 2.0e9 || (prec != kPrecF32 && kp < 224)) return hipErrorInvalidValue;
   const long tiles = (long)n * ((hp + kPoolPH - 1) / kPoolPH) * ((wp + kPoolPW - 1) / kPoolPW);
-  const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);   // persistent, one 8-wave workgroup per CU
+  const long cap = prec == kPrecBf16 ? 512 : 256;                 // persistent: one 8-wave workgroup per CU (bf16: two)
+  const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
   if (prec == kPrecF32)
     hipLaunchKernelGGL(stem_pool_f32_kernel, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
   else if (prec == kPrecBf16)
