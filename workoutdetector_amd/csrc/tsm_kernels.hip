@@ -2824,7 +2824,8 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
   const unsigned x_frame = (unsigned)hi * wpairs * GB, y_frame = (unsigned)hp * wp * OPX;
   const float floor_ = relu ? 0.f : -INFINITY;
   const int tiles_x = (wp + kPoolPW - 1) / kPoolPW, tiles_y = (hp + kPoolPH - 1) / kPoolPH;
-  const long n_tiles = (long)n * tiles_y * tiles_x;
+  const int tiles_f = tiles_x * tiles_y;
+  const int n_tiles = n * tiles_f;                 // (< 2^31: checked by the launcher)
 
   // MFMA row i of the workgroup = conv pixel (i / 17, i % 17) of the tile; row 255 repeats the last pixel
   const int mi = wave * 32 + l31;
@@ -2836,8 +2837,8 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
   constexpr int PCH = kPoolPR * kPoolPC * GB / 16;
   constexpr int PPASS = (PCH + NT - 1) / NT;
   u32x4 pre[PPASS];
-  auto fetch_patch = [&](long t) {
-    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+  auto fetch_patch = [&](int t) {
+    const int f = t / tiles_f, rem = t - f * tiles_f, ty = rem / tiles_x, tx = rem - ty * tiles_x;
     // conv tile origin (2*py0 - 1, 2*px0 - 1)  ->  input rows from 2*(2*py0 - 1) - 3, pairs from (2*px0 - 1) - 2
     const int iy0 = 4 * ty * kPoolPH - 5, pc0 = 2 * tx * kPoolPW - 3;
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
@@ -2853,9 +2854,9 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
       pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)(ok ? off : kInvalid), 0, 0);
     }
   };
-  if ((long)blockIdx.x < n_tiles) fetch_patch(blockIdx.x);
-  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+  if ((int)blockIdx.x < n_tiles) fetch_patch((int)blockIdx.x);
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int f = t / tiles_f, rem = t - f * tiles_f, ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int py0 = ty * kPoolPH, px0 = tx * kPoolPW;
     const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;   // conv pixel of tile position (0, 0)
     const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
@@ -2890,30 +2891,47 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc[1], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc[1], 0, 0, 0);
       } else {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[1], 0, 0, 0);
+        // bf16: the product TRANSPOSED (A = weights, B = pixels; the same products in the same order per accumulator):
+        // a lane then owns ONE conv pixel and 4-channel groups, which makes the epilogue below cheap (the stem is bound
+        // by its vector-ALU instruction count: 376 per wave and tile against 28 MFMAs before this, PMC)
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, ah, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, ah, acc[1], 0, 0, 0);
       }
     }
     // conv tile -> LDS as the values the format would hold: bias, ReLU, round (bf16) or split + re-sum (split-bf16);
     // conv pixels outside the image become -inf so that they never win the maximum (max-pool padding)
+    if constexpr (X3) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float bcol = bias[j * 32 + l31];
+      for (int j = 0; j < 2; ++j) {
+        const float bcol = bias[j * 32 + l31];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        const int r = row / kPoolCC, c = row - r * kPoolCC;
-        const bool inside = row < kPoolCR * kPoolCC && (unsigned)(oy0 + r) < (unsigned)ho && (unsigned)(ox0 + c) < (unsigned)wo;
-        float v = fmaxf(acc[j][e] + bcol, floor_);
-        if constexpr (X3) {
+        for (int e = 0; e < 16; ++e) {
+          const int row = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int r = row / kPoolCC, c = row - r * kPoolCC;
+          const bool inside = row < kPoolCR * kPoolCC && (unsigned)(oy0 + r) < (unsigned)ho && (unsigned)(ox0 + c) < (unsigned)wo;
+          float v = fmaxf(acc[j][e] + bcol, floor_);
           unsigned hw, lw;
           split_pair(v, 0.f, &hw, &lw);
           v = __builtin_bit_cast(float, hw << 16) + __builtin_bit_cast(float, lw << 16);
           Cs[row * 68 + j * 32 + l31] = inside ? v : -INFINITY;
-        } else {   // the value the format stores, as its 16 bits (0xFF80 = -inf)
-          Cs16[row * 72 + j * 32 + l31] = inside ? (unsigned short)(pack_bf16(v, 0.f) & 0xFFFFu) : (unsigned short)0xFF80u;
         }
       }
+    } else {
+      // lane = conv pixel mi (one inside-test), acc[j][4 q + i] = channel 32 j + 8 q + 4 half + i: four bf16 bit patterns
+      // (0xFF80 = -inf) per 8-byte LDS write
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const bool inside = mi < kPoolCR * kPoolCC && (unsigned)(oy0 + mr) < (unsigned)ho && (unsigned)(ox0 + mc) < (unsigned)wo;
+      const u32x2 ninf = {0xFF80FF80u, 0xFF80FF80u};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + j * 32 + 8 * q + 4 * half);
+          u32x2 o;
+          o[0] = pack_bf16(fmaxf(acc[j][4 * q] + b[0], floor_), fmaxf(acc[j][4 * q + 1] + b[1], floor_));
+          o[1] = pack_bf16(fmaxf(acc[j][4 * q + 2] + b[2], floor_), fmaxf(acc[j][4 * q + 3] + b[3], floor_));
+          *reinterpret_cast<u32x2 *>(Cs16 + mi * 72 + j * 32 + 8 * q + 4 * half) = inside ? o : ninf;
+        }
     }
     __syncthreads();
     if (tid < kPoolPH * kPoolPW * 8) {  // one 8-channel group of one pooled pixel per thread
@@ -3091,6 +3109,7 @@ hipError_t launch_stem_pool(const float *x, const float *w, const float *bias, f
   if (prec != kPrecBf16 && prec != kPrecBf16x3 && prec != kPrecF32) return hipErrorInvalidValue;
   if ((double)hi * wi * 16.0 > 2.0e9 || (prec != kPrecF32 && kp < 224)) return hipErrorInvalidValue;
   const long tiles = (long)n * ((hp + kPoolPH - 1) / kPoolPH) * ((wp + kPoolPW - 1) / kPoolPW);
+  if (tiles >= (1L << 31) - 1024) return hipErrorInvalidValue;
   const long cap = prec == kPrecBf16 ? 512 : 256;                 // persistent: one 8-wave workgroup per CU (bf16: two)
   const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
   if (prec == kPrecF32)
