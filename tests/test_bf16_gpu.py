@@ -298,3 +298,34 @@ def test_weight_stationary_kernels_forced_everywhere_equal_the_igemm_engine_bitw
         eng.close()
     for a, c in zip(got['ws'], got['64x64']):
         assert np.array_equal(a, c)
+
+
+def _random_ws_cases():
+    """Seeded random shapes for the weight-stationary kernels: (kind, cin, cout, n, h, w, T)."""
+    rng = np.random.default_rng(20260)
+    cases = []
+    for _ in range(6):
+        cases.append(('3x3', 64, 64, int(rng.integers(1, 40)), int(rng.integers(3, 70)), int(rng.integers(3, 70)), 0))
+        cases.append(('3x3', 128, 128, int(rng.integers(1, 40)), int(rng.integers(3, 40)), int(rng.integers(3, 40)), 0))
+        t = int(rng.choice([0, 2, 3, 4, 8]))
+        cin, cout = [(64, 64), (256, 64), (256, 128), (512, 128), (512, 256)][int(rng.integers(0, 5))]
+        cases.append(('1x1', cin, cout, max(t, 1) * int(rng.integers(1, 6)), int(rng.integers(2, 40)), int(rng.integers(2, 40)), t))
+    return cases
+
+
+@pytest.mark.parametrize('kind,cin,cout,n,hi,wi,shiftT', _random_ws_cases())
+def test_weight_stationary_kernels_on_random_shapes_bitwise(hip_lib, monkeypatch, kind, cin, cout, n, hi, wi, shiftT):
+    """Seeded random frame counts / sizes / segment counts (ragged tiles, tiles straddling frames and clips, frames
+    smaller than a tile) through every weight-stationary kernel family, bit-compared with the 64x64 igemm tile."""
+    from workoutdetector_amd.engine import conv_bn_act_nhwc
+    k = 3 if kind == '3x3' else 1
+    g = torch.Generator().manual_seed(n * 1000 + hi * 10 + wi + cin)
+    x = torch.randn(n, cin, hi, wi, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    bn = _bn(cout, g)
+    outs = {}
+    for tile in ('ws', '64x64'):
+        monkeypatch.setenv('TSM_CONV_TILE', tile)
+        outs[tile] = conv_bn_act_nhwc(_nhwc(x).cuda(), w.cuda(), *[b.cuda() for b in bn], stride=1, relu=True,
+                                      shift_segments=shiftT, fold_div=8, dtype='bf16').cpu()
+    assert torch.equal(outs['ws'], outs['64x64'])
