@@ -5,17 +5,20 @@
 
 A "step" is one pass of the hot path (HIP engine forward, tsm_forward through the C ABI) over one
 batch of 32 synthetic clips [32, 8, 3, 224, 224] fp32 that is already resident in HBM (BASELINE.json
-configs[1]).  N > 1: one process per GPU under torch.distributed.run; clips are independent units so
-every rank runs its own batch (weak scaling) and the only exchange is the RCCL all-gather of per-clip
-logits, which is inside the timed step.  Rank 0 prints ONE JSON line.
+configs[1]).  N > 1: one process per GPU -- either under a launcher (`python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment)
+or, when WORLD_SIZE is unset, started by this script itself before it touches the GPU (`self_launch`);
+clips are independent units so every rank runs its own batch (weak scaling) and the only exchange is the
+RCCL all-gather of per-clip logits, which is inside the timed step.  All ranks share one tile-tuning pass
+(TSM_TUNE_CACHE: rank 0 tunes, the others read).  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant kernel is the conv_igemm<BM,BN,WGM,WGN,3,false,false,PREC,false,SEG> instantiation the engine's
-                autotuner picked for the 3x3 convolutions of layer2..layer4 (13 launches per forward, one
-                third of the forward's time; if the tuner split them over two tile shapes, the shape with
-                the larger total).  Every one of
-                those launches does the same algorithmic work, 115.6 MMAC/frame x 2 x frames (59.19 GFLOP
-                at batch 32); `achieved` = that / the launches' average duration, measured with HIP-event
+  roofline      the dominant kernel is the kernel the engine's autotuner runs the 3x3 convolutions of
+                layer2..layer4 on (13 launches per forward, one third of the forward's time; `kernel_of` maps the
+                tuner's tile code to the kernel name rocprofv3 prints; if the tuner split them over several
+                kernels, the one with the larger total).  Every plain 3x3 launch does the same algorithmic work,
+                115.6 MMAC/frame x 2 x frames (59.19 GFLOP at batch 32); a launch that also runs its block's conv3
+                is a different kernel and is priced with both convs; `achieved` = work / the launches' average duration, measured with HIP-event
                 pairs recorded around each launch on the launch stream during the timed steps
                 (tsm_set_layer_timing / tsm_layer_times), against the exact-fp32 MFMA peak (157.3 TFLOP/s,
                 MI355X_MICROARCH.md).  `forward_achieved` / `forward_frac` price the whole forward
@@ -116,6 +119,73 @@ def cpu_baseline(sd_np, t, h, w, budget_s=15.0):
                       f'(reference onnxruntime CPU path not runnable here)'}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n, script=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher: this process -- which has not imported torch, let alone
+    touched the GPU -- starts N fresh children of itself, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+    torch.distributed.run would set them; the reference's launcher for comparison: tools/dist_train.sh:3-10), lets rank
+    0's JSON line through on the inherited stdout and exits with the worst child code.  All ranks share one
+    TSM_TUNE_CACHE file: rank 0 tunes, the others read its choices (main(), `tuned_engine`)."""
+    import subprocess
+    import tempfile
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    tune = os.environ.get('TSM_TUNE_CACHE')
+    tmpdir = None
+    if not tune:
+        tmpdir = tempfile.mkdtemp(prefix='tsm_bench_')
+        tune = os.path.join(tmpdir, 'tune_cache.txt')
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=port, TSM_TUNE_CACHE=tune,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + sys.argv[1:], env=env))
+    worst, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0) and deadline is None:
+                deadline = time.monotonic() + 30.0       # a rank died: the others are stuck in a collective
+        if deadline is not None and time.monotonic() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                              # exactly the PIDs started above
+        time.sleep(0.2)
+    for p in procs:
+        rc = p.wait()
+        worst = rc if (rc != 0 and worst == 0) else worst
+    if tmpdir:
+        import shutil
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return worst
+
+
+def kernel_of(tile, dtype, cmid):
+    """rocprofv3's name (minus `void tsm::` and the parameter list) of the kernel a 3x3 launch with tile name `tile`
+    (TsmEngine.tile_name) runs, and whether that launch also does the block's conv3 (+ residual)."""
+    fused = tile.endswith('+conv3')
+    main = tile.replace('+conv3', '').split('/')[0]
+    if main == 'ws':
+        if cmid == 64:
+            return 'conv3x3_ws_kernel<%s>' % ('true' if fused else 'false'), fused
+        return 'conv3x3_ws128_kernel', fused
+    if fused:
+        return 'conv23_fused_kernel<%d, %s>' % (cmid, 'true' if dtype == 'bf16x3' else 'false'), True
+    if main == '256x256':
+        return 'conv_bf16_256_kernel<3, false, false, false>', False
+    waves = '1, 1' if main == '32x32' else '4, 2' if main.endswith('w8') else '2, 2'
+    prec_id = {'f32': 0, 'bf16x3': 1, 'bf16': 2}[dtype]
+    # template arguments: BM, BN, WGM, WGN, KS, SHIFT, RES, PREC, DUAL, SEG (fp32 long-K layers accumulate K in segments)
+    return 'conv_igemm<%s, %s, 3, false, false, %d, false, %s>' % (
+        main.replace('w8', '').replace('x', ', '), waves, prec_id, 'true' if dtype == 'f32' else 'false'), False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -136,6 +206,10 @@ def main():
         args.dtype, args.batch, args.segments, args.size = 'bf16', 64, 16, 256
         args.no_alt = args.no_cpu_baseline = True
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # the driver's command form for N > 1 may come without a launcher: start the ranks ourselves, BEFORE torch
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -143,8 +217,6 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the product path)'
     # Rehearsal hook for boxes with fewer GPUs than ranks (TSM_BENCH_REHEARSAL=1): all ranks share cuda:0 and
@@ -169,6 +241,17 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     collective = world > 1 or forced
     backend = dist.get_backend() if collective else None
+    # One tile-tuning pass per job, not per rank: every rank points at the same TSM_TUNE_CACHE file (self_launch sets
+    # it; under an external launcher rank 0 names one here), rank 0 creates + tunes its engine first, the others
+    # read its choices.  Tile choices never change a result bit, but ranks on different choices would time
+    # different kernels.
+    if world > 1:
+        name = [os.environ.get('TSM_TUNE_CACHE')]
+        if name[0] is None and rank == 0:
+            import tempfile
+            name[0] = os.path.join(tempfile.mkdtemp(prefix='tsm_bench_'), 'tune_cache.txt')
+        dist.broadcast_object_list(name, src=0, device=torch.device('cpu') if rehearsal else torch.device('cuda', local_rank))
+        os.environ['TSM_TUNE_CACHE'] = name[0]
 
     from workoutdetector_amd.build import build_library
     if rank == 0:
@@ -188,10 +271,14 @@ def main():
 
     def run_mode(dtype, want_launch_times):
         """W warm-up + K timed steps of one engine; returns wall seconds (max over ranks) and event timings."""
+        if world > 1 and rank != 0:
+            dist.barrier()       # rank 0 is tuning; its choices are in TSM_TUNE_CACHE when this returns
         eng = TsmEngine(num_class=12, num_segments=T, height=H, width=W, max_clips=B, device=local_rank,
                         state_dict=sd, dtype=dtype)
         logits = torch.empty(B, 12, device='cuda')
         eng.warmup([B])      # one-time tile / split-K autotuning of this batch size: initialisation, never a timed step
+        if world > 1 and rank == 0:
+            dist.barrier()
 
         def step():
             eng.forward_device(clips, out=logits)
@@ -235,6 +322,9 @@ def main():
         t_max = torch.tensor([elapsed], device='cuda')
         if collective:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+            sm = step_ms[dtype]
+            mine = torch.tensor([[sm[len(sm) // 2], sorted(fwd_ev_ms)[len(fwd_ev_ms) // 2]]], device='cuda')
+            rank_ms[dtype] = all_gather_logits(mine).cpu().tolist()      # [world][step median, forward-kernel median]
             # the exchange step on its own ("all-gather us"), outside the timed region
             torch.cuda.synchronize()
             dist.barrier()
@@ -247,7 +337,7 @@ def main():
         eng.close()
         return float(t_max.item()), per_launch, sorted(fwd_ev_ms)[len(fwd_ev_ms) // 2], tiles
 
-    exchange_us, step_ms = {}, {}
+    exchange_us, step_ms, rank_ms = {}, {}, {}
     elapsed, per_launch, fwd_ms, tiles = run_mode(args.dtype, True)
     alt = None
     if not args.no_alt:
@@ -262,24 +352,24 @@ def main():
         fwd_achieved = gflop * B / fwd_ms  # GFLOP / ms == TFLOP/s
         from workoutdetector_amd.flops import layer_table
         frames = B * T
-        dom = [r for r in layer_table(H, W) if r['k'] == 3 and r['s'] >= 1 and not r['name'].startswith('layer1.')]
-        dom_gflop = {2.0 * r['macs'] * frames / 1e9 for r in dom}
-        assert len(dom_gflop) == 1, 'every 3x3 conv of ResNet-50 does the same work per frame'
-        dom_gflop = dom_gflop.pop()
-        # The engine tunes the tile shape per layer, so the 3x3 convs may run on more than one
-        # instantiation of conv_igemm: the dominant kernel is the instantiation with the most time.
+        table = {r['name']: r for r in layer_table(H, W)}
+        dom = [r for r in table.values() if r['k'] == 3 and r['s'] >= 1 and not r['name'].startswith('layer1.')]
+        # The engine tunes the tile shape (and the conv2 + conv3 fusion) per layer, so the 3x3 convs may run on more
+        # than one kernel: the dominant kernel is the one with the most time.  A fused launch is priced with the
+        # work it really does (its block's conv3 on top of the 3x3) and never mixed into the plain-3x3 group.
         groups = {}
         for r in dom:
-            groups.setdefault(tiles[r['name']], []).extend(d[r['name']] for d in per_launch)
-        dom_tile, dom_ms = max(groups.items(), key=lambda kv: sum(kv[1]))
-        prec_id = {'f32': 0, 'bf16x3': 1, 'bf16': 2}[args.dtype]
-        main_tile = dom_tile.split('/')[0]
-        waves = '1, 1' if main_tile == '32x32' else '4, 2' if main_tile.endswith('w8') else '2, 2'
-        # template arguments: BM, BN, WGM, WGN, KS, SHIFT, RES, PREC, DUAL, SEG (fp32 long-K layers accumulate K in segments)
-        dom_kernel = 'conv_igemm<%s, %s, 3, false, false, %d, false, %s>' % (
-            main_tile.replace('w8', '').replace('x', ', '), waves, prec_id, 'true' if args.dtype == 'f32' else 'false')
-        if main_tile == '256x256':      # the LDS-DMA 256 x 256 bf16 kernel has its own name
-            dom_kernel = "conv_bf16_256_kernel<3, false, false, false>"
+            kern, with_conv3 = kernel_of(tiles[r['name']], args.dtype, r['cout'])
+            gf = 2.0 * r['macs'] * frames / 1e9
+            if with_conv3:
+                gf += 2.0 * table[r['name'].replace('.conv2', '.conv3')]['macs'] * frames / 1e9
+            g = groups.setdefault(kern, {'ms': [], 'gflop': []})
+            for d in per_launch:
+                g['ms'].append(d[r['name']])
+                g['gflop'].append(gf)
+        dom_kernel, g = max(groups.items(), key=lambda kv: sum(kv[1]['ms']))
+        dom_ms = g['ms']
+        dom_gflop = sum(g['gflop']) / len(g['gflop'])
         peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         peak_name = ('dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); the kernel executes 3 MFMA FLOPs per algorithmic FLOP'
                      if args.dtype == 'bf16x3' else 'dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)' if args.dtype == 'bf16'
@@ -317,8 +407,10 @@ def main():
                          'traffic': (traffic_entry or {}).get('hbm_bytes_per_launch'),
                          **({'traffic_stale': traffic_stale} if traffic_stale else {}),
                          'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/traffic.json)',
-                         'kernel': dom_kernel + ' (3x3 convs of layer2-4, %d of 13 launches per forward)'
-                                   % (len(dom_ms) // len(per_launch)),
+                         'kernel': dom_kernel + ' (3x3 convs of layer2-4%s, %d of 13 launches per forward)'
+                                   % (', each with its block\'s conv3 + residual fused behind it'
+                                      if dom_gflop > 1.01 * 2.0 * dom[0]['macs'] * frames / 1e9 else '',
+                                      len(dom_ms) // len(per_launch)),
                          'gflop_per_launch': round(dom_gflop, 3), 'avg_launch_ms': round(dom_avg_ms, 4),
                          'launches_timed': len(dom_ms),
                          'peak_name': peak_name,
@@ -338,6 +430,10 @@ def main():
             line['exchange'] = {'collective': 'all_gather_into_tensor of f32[%d, 12] per rank (backend %s%s)'
                                               % (B, backend, ' = RCCL' if backend == 'nccl' else ': NOT RCCL, rehearsal'),
                                 'avg_us': round(exchange_us[args.dtype], 1),
+                                'per_rank_step_ms_median': [round(r[0], 4) for r in rank_ms[args.dtype]],
+                                'per_rank_forward_kernel_ms_median': [round(r[1], 4) for r in rank_ms[args.dtype]],
+                                'tune_cache': 'one TSM_TUNE_CACHE file for all ranks: rank 0 tunes, the others read its '
+                                              'tile choices' if world > 1 else 'single rank',
                                 'note': 'back-to-back latency of the only data-path collective, measured outside the timed steps'}
         if alt is not None:
             a_dtype, a_elapsed, a_fwd = alt

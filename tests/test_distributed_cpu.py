@@ -122,3 +122,102 @@ def test_video_sharded_inference_dataset_equals_single_process(tmp_path, golden_
     ic.inference_dataset(StubModel(), ['test'], alone, checkpoint='stub', data_root=str(root), shard='videos')
     for f in os.listdir(single):
         assert json.load(open(os.path.join(single, f))) == json.load(open(os.path.join(alone, f)))
+
+
+def _dataset_global_worker(rank, world, root, out_dir, batch):
+    from tests._stub import StubModel
+    from workoutdetector_amd import inference_count as ic
+    calls = {'n': 0}
+    real = dist.all_gather_into_tensor
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+
+    dist.all_gather_into_tensor = counting
+    model = StubModel()
+    ic.inference_dataset(model, ['test'], out_dir, checkpoint='stub', data_root=root, batch_clips=batch)   # default shard
+    # no collective inside the loop: the whole job exchanges twice (video table, then the logits), whatever its size
+    assert calls['n'] == 2, calls
+    open(os.path.join(out_dir, f'calls{rank}'), 'w').write(str(model.calls))
+
+
+GLOBAL_FRAMES = (77, 9, 41, 160, 8, 23, 95, 64, 130, 17)      # 10 / 2 / 6 / 20 / 1 / 3 / 12 / 8 / 17 / 3 clips
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_globally_sharded_inference_dataset_equals_single_process(tmp_path, golden_dir, world):
+    """shard='global' (the default for W > 1): whole videos to ranks longest-first by clip count, cross-video batches,
+    ONE exchange at the end, rank 0 writes: the JSON files are byte-identical to the single-process run at W = 2, 3
+    and 8 (W = 8 > the number of long videos: some ranks own one short video)."""
+    import pandas as pd
+    from tests._stub import StubModel, synthetic_video
+    from workoutdetector_amd import inference_count as ic
+    anno = pd.read_csv(f'{golden_dir}/repcount_annotation.csv', index_col=0)
+    from workoutdetector_amd.repcount import CLASSES
+    rows = anno[(anno['split'] == 'test') & anno['class_'].isin(CLASSES)].head(len(GLOBAL_FRAMES)).copy()
+    rows['name'] = [n.replace('.mp4', '.npy') for n in rows['name']]
+    root = tmp_path / 'RepCount'
+    (root / 'videos' / 'test').mkdir(parents=True)
+    rows.to_csv(root / 'annotation.csv')
+    for i, name in enumerate(rows['name']):
+        np.save(root / 'videos' / 'test' / name, synthetic_video(i, GLOBAL_FRAMES[i], 40 + 2 * (i % 3), 30))
+    single, sharded = str(tmp_path / 'single'), str(tmp_path / 'sharded')
+    ic.inference_dataset(StubModel(), ['test'], single, checkpoint='stub', data_root=str(root))
+    os.makedirs(sharded)
+    _spawn(_dataset_global_worker, str(root), sharded, 4, world=world)
+    files = sorted(f for f in os.listdir(sharded) if f.endswith('.json'))
+    assert files == sorted(os.listdir(single)) and len(files) == len(GLOBAL_FRAMES)
+    for f in files:
+        assert open(os.path.join(single, f)).read() == open(os.path.join(sharded, f)).read(), f
+    # full cross-video batches: the ranks together ran ceil(clips_on_rank / 4) forwards each, not one ragged tail per video
+    clips = [len(range(0, f, 8)) for f in GLOBAL_FRAMES]
+    owner = tdist.plan_video_shards(clips, world)
+    for r in range(world):
+        mine = sum(c for c, o in zip(clips, owner) if o == r)
+        assert int(open(os.path.join(sharded, f'calls{r}')).read()) == -(-mine // 4), (r, mine)
+    # the single-process form of the same mode
+    alone = str(tmp_path / 'alone')
+    ic.inference_dataset(StubModel(), ['test'], alone, checkpoint='stub', data_root=str(root), shard='global', batch_clips=5)
+    for f in files:
+        assert open(os.path.join(single, f)).read() == open(os.path.join(alone, f)).read(), f
+
+
+def test_global_shard_plan_is_balanced_on_the_repcount_val_distribution(golden_dir):
+    """BASELINE config 4's own distribution (100 val videos, 2-327 clips, 10 062 in all, from the committed annotation):
+    the longest-first plan keeps every rank within 5 % of the mean up to W = 8 with no exchange until the end, where
+    round-2's lock-stepped round-robin (an exchange per round of W videos) modelled at 0.72 / 0.56 / 0.45."""
+    import pandas as pd
+    anno = pd.read_csv(f'{golden_dir}/repcount_annotation.csv', index_col=0)
+    val = anno[(anno.split == 'val') & anno.class_.isin(['situp', 'push_up', 'pull_up', 'jump_jack', 'squat', 'front_raise'])]
+    clips = []
+    for _, r in val.iterrows():
+        reps = [int(v) for v in str(r['reps']).split()] if int(r['count']) > 0 else []
+        clips.append(len(range(0, max(max(reps) if reps else 0, 16), 8)))
+    assert len(clips) == 100 and sum(clips) == 10062
+    for world, old in ((2, 0.73), (4, 0.57), (8, 0.45)):
+        owner = tdist.plan_video_shards(clips, world)
+        assert sorted(set(owner)) == list(range(world))
+        assert tdist.shard_efficiency(clips, owner, world) >= 0.95
+        assert tdist.lockstep_efficiency(clips, world) <= old
+    assert tdist.plan_video_shards(clips, 1) == [0] * 100
+    # estimates from the annotation alone (no frame files): the same plan on every rank, any order of evaluation
+    assert tdist.plan_video_shards(clips, 8) == tdist.plan_video_shards(list(clips), 8)
+
+
+def test_bench_self_launch_propagates_a_failing_rank_without_hanging():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its own ranks (bench.self_launch).  Without a GPU every
+    rank stops at the product's "no CPU fallback" assertion: the parent must come back with a non-zero code (never
+    hang on the ranks, never print a JSON line, never fall back to a CPU measurement)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('this is the no-GPU failure path')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode != 0
+    assert 'needs a GPU' in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]

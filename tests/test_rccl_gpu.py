@@ -44,7 +44,7 @@ def test_one_rank_nccl_group_drives_the_collective_branch(hip_lib, tmp_path):
                          capture_output=True, text=True, env=_env(), timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     rep = _last_json(out.stdout)
-    assert rep['ok'] and rep['backend'] == 'nccl' and rep['world'] == 1 and rep['collective_calls'] == 11
+    assert rep['ok'] and rep['backend'] == 'nccl' and rep['world'] == 1 and rep['collective_calls'] == 13
 
 
 def test_bench_step_through_a_one_rank_rccl_group(hip_lib):
@@ -74,3 +74,20 @@ def test_rehearsal_line_is_labelled_and_carries_no_value(hip_lib):
     assert line['rehearsal'] is True and line['value'] is None and line['n_gpus'] == 2
     assert line['config']['parallelism'].startswith('REHEARSAL') and 'NOT RCCL' in line['exchange']['collective']
     assert 'RCCL (nccl' not in line['config']['parallelism']
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_given(hip_lib):
+    """`python3 bench.py --gpus 2` with WORLD_SIZE unset (the driver's plain command form): the parent spawns the two
+    ranks before touching the GPU, they share ONE tune cache (rank 0 tunes, rank 1 reads), rank 0's single JSON line
+    comes through the parent's stdout and carries per-rank step medians.  Rehearsal: both ranks on this box's one GPU."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                          '--batch', '2', '--no-alt', '--no-cpu-baseline'], capture_output=True, text=True, timeout=900,
+                         env=_env(TSM_BENCH_REHEARSAL='1'), cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    json_lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(json_lines) == 1, out.stdout[-3000:]
+    line = json.loads(json_lines[0])
+    assert line['rehearsal'] is True and line['n_gpus'] == 2 and line['value'] is None
+    ex = line['exchange']
+    assert len(ex['per_rank_step_ms_median']) == 2 and all(v > 0 for v in ex['per_rank_step_ms_median'])
+    assert len(ex['per_rank_forward_kernel_ms_median']) == 2 and 'rank 0 tunes' in ex['tune_cache']

@@ -8,6 +8,12 @@
   config 5  T=16, 256x256, 64 clips per GPU, TSM_DTYPE_BF16 (and the exact-f32 mode on the same shape)
 
     python tools/bench_configs.py [--dtype f32|bf16x3] > gpurun_out/configs.json
+
+  config 4, strong scaling over N GPUs (fixed job: the 100 RepCount-val videos / 10 062 clips of the committed
+  annotation, `inference_dataset(shard='global')`: videos to ranks longest-first, no collective in the loop, one
+  exchange at the end, rank 0 writes the 100 JSON files):
+
+    python tools/bench_configs.py --config 4 --gpus N [--dtype ...]      (starts its own N ranks, like bench.py)
 """
 import argparse
 import json
@@ -15,11 +21,17 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+if __name__ == '__main__' and '--gpus' in sys.argv and 'WORLD_SIZE' not in os.environ:
+    _n = int(sys.argv[sys.argv.index('--gpus') + 1])
+    if _n > 1:      # start the ranks BEFORE this process imports torch or touches the GPU (same helper as bench.py)
+        import bench
+        sys.exit(bench.self_launch(_n, script=__file__))
+
+import numpy as np
+import torch
 
 from workoutdetector_amd import inference_count as ic  # noqa: E402
 from workoutdetector_amd.counting import pred_to_count, scores_to_preds  # noqa: E402
@@ -135,10 +147,109 @@ def config5(dtype, steps=10, warmup=3, batch=64):
             'algorithmic_tflops': gflop * batch / dt / 1e3}
 
 
+def config4_scaling(args):
+    """One JSON line: clips/s of the whole fixed job (strong scaling), max over ranks of the wall time from the first
+    video read to rank 0's last JSON file, plus the modelled plan efficiency and the per-rank clip loads."""
+    import shutil
+    import tempfile
+    import pandas as pd
+    import torch.distributed as dist
+    from workoutdetector_amd import distributed as tdist
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    rehearsal = os.environ.get('TSM_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if rehearsal:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    anno = pd.read_csv(os.path.join(ROOT, 'tests', 'golden', 'repcount_annotation.csv'), index_col=0)
+    val = anno[(anno.split == 'val') & anno.class_.isin(['situp', 'push_up', 'pull_up', 'jump_jack', 'squat', 'front_raise'])]
+    if args.videos:
+        val = val.head(args.videos)
+    frames = {}
+    for _, r in val.iterrows():
+        reps = [int(v) for v in str(r['reps']).split()] if int(r['count']) > 0 else []
+        frames[r['name']] = max(max(reps) if reps else 0, 16)
+    fh, fw = (int(v) for v in args.frame_size.split('x'))
+    # No decoder / dataset offline: every "decoded" video is a window of one seeded pool of random uint8 frames, so the
+    # reader costs a view, while pinning, H2D, the transform and everything behind them move real bytes.
+    pool = torch.randint(0, 256, (max(frames.values()) + 8, fh, fw, 3), dtype=torch.uint8,
+                         generator=torch.Generator().manual_seed(0))
+
+    def reader(path):
+        return pool[:frames[os.path.basename(path)]]
+
+    def counter(path):
+        return frames[os.path.basename(path)]
+
+    base = os.environ.get('TSM_BENCH_TMP') or tempfile.gettempdir()
+    root = os.path.join(base, 'tsm_config4_job_%s' % os.environ.get('MASTER_PORT', 'solo'))
+    if rank == 0:
+        shutil.rmtree(root, ignore_errors=True)
+        os.makedirs(root)
+        val.to_csv(os.path.join(root, 'annotation.csv'))
+    if world > 1:
+        dist.barrier()
+        if rank != 0:
+            dist.barrier()       # rank 0 tunes first; the others read its choices (shared TSM_TUNE_CACHE)
+    eng = TsmEngine(max_clips=32, state_dict=make_state_dict(0, 12), dtype=args.dtype, device=local_rank)
+    eng.warmup()
+    if world > 1 and rank == 0:
+        dist.barrier()
+    import contextlib
+    import io
+    sync()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ic.inference_dataset(eng, ['val'], os.path.join(root, 'out'), checkpoint='seed0', data_root=root,
+                             video_reader=reader, frame_counter=counter, batch_clips=32)
+    sync()
+    dt = torch.tensor([time.perf_counter() - t0], device='cuda')
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    clips = [len(range(0, f, 8)) for f in frames.values()]
+    owner = tdist.plan_video_shards(clips, world)
+    if rank == 0:
+        n_files = len(os.listdir(os.path.join(root, 'out')))
+        assert n_files == len(frames), (n_files, len(frames))
+        load = [sum(c for c, o in zip(clips, owner) if o == r) for r in range(world)]
+        print(json.dumps({
+            'metric': 'clips/sec, RepCount-val-shaped dataset run end to end (BASELINE.json configs[3])',
+            'value': None if rehearsal else round(sum(clips) / float(dt.item()), 2), 'unit': 'clips/s', 'n_gpus': world,
+            'scaling': 'strong', 'dtype': args.dtype, 'videos': len(frames), 'clips': sum(clips),
+            'job_s': round(float(dt.item()), 4), 'frame_size': args.frame_size, 'clips_per_rank': load,
+            'plan_efficiency': round(tdist.shard_efficiency(clips, owner, world), 4),
+            'lockstep_round_robin_efficiency': round(tdist.lockstep_efficiency(clips, world), 4),
+            **({'rehearsal': True} if rehearsal else {}),
+            'note': 'inference_dataset(shard="global"): whole videos to ranks longest-first, per rank pin + H2D of uint8 '
+                    'frames (prefetched one video ahead), fused HIP transform, engine in full cross-video batches of 32, '
+                    'no collective inside the loop, one D2H per rank, ONE exchange at the end (video table + padded '
+                    'logits), rank 0 writes the JSON files; time = max over ranks, barrier to last file'}), flush=True)
+        shutil.rmtree(root, ignore_errors=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--dtype', default='f32')
+    ap.add_argument('--config', type=int, default=0, help='4: the strong-scaling dataset run (with --gpus N)')
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--videos', type=int, default=0, help='config 4: only the first N val videos (rehearsals)')
+    ap.add_argument('--frame-size', default='360x206', help='config 4: HxW of the synthetic decoded frames')
     args = ap.parse_args()
+    if args.config == 4:
+        config4_scaling(args)
+        return
     eng = TsmEngine(max_clips=32, state_dict=make_state_dict(0, 12), dtype=args.dtype)
     res = {'engine_dtype': args.dtype, 'config3': config3(eng), 'config4': config4(eng)}
     eng.close()

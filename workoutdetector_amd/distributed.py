@@ -11,7 +11,7 @@ Backend: ``nccl`` (= RCCL over xGMI on ROCm) for CUDA tensors, ``gloo`` for the 
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -87,3 +87,35 @@ def gather_clip_logits(local: torch.Tensor, n_total: int, group=None) -> torch.T
 def shard_list(items: List, world: int, rank: int) -> List:
     lo, hi = shard_range(len(items), world, rank)
     return items[lo:hi]
+
+
+# ---- dataset-level sharding: whole videos over ranks, balanced by clip count -------------------------------------
+def plan_video_shards(clip_counts: Sequence[int], world: int) -> List[int]:
+    """Owner rank of every video for a dataset run (BASELINE config 4): longest-processing-time-first -- videos in
+    order of decreasing (estimated) clip count, each to the rank with the fewest clips so far (ties: lowest video
+    index / lowest rank).  Deterministic, so every rank computes the same plan from the same counts with no exchange.
+    The counts only steer the balance; a wrong estimate costs speed, never correctness."""
+    load = [0] * world
+    owner = [0] * len(clip_counts)
+    for v in sorted(range(len(clip_counts)), key=lambda i: (-int(clip_counts[i]), i)):
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[v] = r
+        load[r] += int(clip_counts[v])
+    return owner
+
+
+def shard_efficiency(clip_counts: Sequence[int], owner: Sequence[int], world: int) -> float:
+    """Modelled strong-scaling efficiency of a plan whose ranks run independently until ONE final exchange:
+    (total clips / W) / (clips of the busiest rank)."""
+    load = [0] * world
+    for c, r in zip(clip_counts, owner):
+        load[r] += int(c)
+    return (sum(load) / world) / max(load) if max(load) > 0 else 1.0
+
+
+def lockstep_efficiency(clip_counts: Sequence[int], world: int) -> float:
+    """The same figure for round-robin rounds of W videos with an exchange per round (``shard='videos'``): every round
+    lasts as long as its longest video."""
+    total = sum(int(c) for c in clip_counts)
+    span = sum(max(int(c) for c in clip_counts[r0:r0 + world]) for r0 in range(0, len(clip_counts), world))
+    return (total / world) / span if span > 0 else 1.0

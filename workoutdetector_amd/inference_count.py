@@ -18,9 +18,11 @@ What differs from the reference, on purpose:
   * videos come from a pluggable ``video_reader`` (the image has no H.264 decoder): ``.npy`` files of
     uint8 [F,H,W,3] frames are read natively, anything else goes to ``torchvision.io.read_video`` when
     that is importable.
-  * under ``torch.distributed`` the clips of each video are sharded across ranks in contiguous blocks
-    and the per-clip logits are all-gathered once per video (RCCL over xGMI with the nccl backend);
-    rank 0 writes the JSON.  ``shard='videos'`` shards whole videos instead (each decoded once).
+  * under ``torch.distributed`` a dataset run lays out the global (video, clip) index once: whole videos go to
+    ranks longest-first by clip count, every rank runs full batches with no collective in its loop, and the
+    per-clip logits are all-gathered ONCE at the end (RCCL over xGMI with the nccl backend); rank 0 writes the
+    JSON (``shard='global'``).  ``shard='clips'`` splits the clips of each video instead (one all-gather per
+    video: the single-stream latency form); ``shard='videos'`` is the lock-stepped round-robin of round 2.
   * ``count_by_video_model`` in the reference snapshot is broken (asserts on the missing transform and
     always reads class 0 from an unsorted list, :270,:276,:327); this one implements the documented
     intent: arg-max class of each non-overlapping 8-frame window, softmax + threshold as in
@@ -133,25 +135,39 @@ class StagedVideo:
 class _PinnedPool:
     """Reusable page-locked staging buffers.  Pinning fresh memory for every video costs a hipHostMalloc /
     hipHostFree pair that serialises with the GPU queue; here a few flat byte buffers are grown geometrically
-    and handed out round-robin, each only after the H2D copy that last read it has completed."""
+    and handed out round-robin.  Ownership is explicit: ``take`` hands a slot to exactly one user (the prefetch
+    worker thread and the main thread's oversized-video loop share the pool) and the slot stays taken -- while it
+    is being filled on the host AND while the H2D copy out of it is in flight -- until that user calls ``release``
+    with the event recorded behind its copy; the next taker of the slot waits for the release, then for the event."""
 
     def __init__(self, slots: int = 3):
         self.bufs: List[Optional[torch.Tensor]] = [None] * slots
         self.busy: List[Optional[object]] = [None] * slots      # event of the last copy out of the slot
+        self.taken: List[bool] = [False] * slots                # handed out and not yet released
         self.next = 0
-        self.lock = threading.Lock()        # the prefetch worker thread and a StreamBatcher may share the pool
+        self.cv = threading.Condition()
 
     def take(self, nbytes: int) -> Tuple[torch.Tensor, int]:
-        with self.lock:
+        with self.cv:
             i = self.next
             self.next = (i + 1) % len(self.bufs)
-        if self.busy[i] is not None:
-            self.busy[i].synchronize()
-            self.busy[i] = None
+            while self.taken[i]:
+                self.cv.wait()
+            self.taken[i] = True
+            ev, self.busy[i] = self.busy[i], None
+        if ev is not None:
+            ev.synchronize()
         if self.bufs[i] is None or self.bufs[i].numel() < nbytes:
             self.bufs[i] = None                                  # free before growing
             self.bufs[i] = torch.empty(max(nbytes, 1 << 20) * 5 // 4, dtype=torch.uint8, pin_memory=True)
         return self.bufs[i][:nbytes], i
+
+    def release(self, slot: int, event: Optional[object]) -> None:
+        """The user's host fill is done and its H2D copy is enqueued; ``event`` completes when the copy has."""
+        with self.cv:
+            self.busy[slot] = event
+            self.taken[slot] = False
+            self.cv.notify_all()
 
 
 _pinned_pool = _PinnedPool()
@@ -180,15 +196,18 @@ def stage_video(model, video_thwc_u8: torch.Tensor, clip_range: Optional[Tuple[i
         return StagedVideo(total, lo, hi, f_lo, hw, even, False)
     shape = (even.shape[0] + 1,) + tuple(even.shape[1:])
     flat, slot = _pinned_pool.take(int(np.prod(shape)))
-    pinned = flat.view(shape)
-    pinned[:-1].copy_(even)
-    pinned[-1].zero_()              # the zero frame the padded tail clip reads
-    ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
-    with ctx:
-        frames = pinned.to(dev, non_blocking=True)
-        ready = torch.cuda.Event()
-        ready.record()
-    _pinned_pool.busy[slot] = ready
+    ready = None
+    try:
+        pinned = flat.view(shape)
+        pinned[:-1].copy_(even)
+        pinned[-1].zero_()              # the zero frame the padded tail clip reads
+        ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+        with ctx:
+            frames = pinned.to(dev, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record()
+    finally:
+        _pinned_pool.release(slot, ready)
     return StagedVideo(total, lo, hi, f_lo, hw, frames, True, ready, pinned)
 
 
@@ -212,27 +231,41 @@ def staged_clip_logits(model, st: StagedVideo, transform: TestTransform, batch_c
             piece = st.frames[f_a - st.f_lo:f_b - st.f_lo]
             shape = (piece.shape[0] + 1,) + tuple(piece.shape[1:])
             flat, slot = _pinned_pool.take(int(np.prod(shape)))
-            pinned = flat.view(shape)
-            pinned[:-1].copy_(piece)
-            pinned[-1].zero_()
-            frames = pinned.to(dev, non_blocking=True)
-            ready = torch.cuda.Event()
-            ready.record()
-            _pinned_pool.busy[slot] = ready
+            ready = None
+            try:
+                pinned = flat.view(shape)
+                pinned[:-1].copy_(piece)
+                pinned[-1].zero_()
+                frames = pinned.to(dev, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record()
+            finally:
+                _pinned_pool.release(slot, ready)
             parts.append(staged_clip_logits(model, StagedVideo(st.total, a, b, f_a, st.hw, frames, True, ready, pinned),
                                             transform, batch_clips))
         return torch.cat(parts, dim=0)
+    frames, idx, hip_transform = _staged_clips(model, st, transform)
+    out = [_forward_clips(model, frames[idx[b:b + batch_clips]], hip_transform)
+           for b in range(0, idx.shape[0], batch_clips)]
+    return torch.cat(out, dim=0).to(torch.float32).cpu()
+
+
+def _staged_clips(model, st: StagedVideo, transform: TestTransform) -> Tuple[torch.Tensor, torch.Tensor, bool]:
+    """Transformed frames of a staged clip range (each frame once), the [n_clips, 8] frame indices of its clips
+    (the zero-padded tail points at one shared zero frame), and whether the frames are in the engine's packed
+    device format (HIP transform) rather than float32 [n,3,224,224]."""
+    starts = clip_starts(st.total)
+    dev = _engine_device(model)
     hip_transform = st.on_device and isinstance(transform, TestTransform)
     if hip_transform:
         # HIP path: uint8 frames (+ one zero frame for the padded tail) -> fused resize/crop/normalise
         # kernel -> the engine's packed input format, consumed in place.
         from .engine import preprocess_frames
-        packed_layout = model.packed_layout
         cur = torch.cuda.current_stream(dev)
         cur.wait_event(st.ready)
         st.frames.record_stream(cur)
         frames = preprocess_frames(st.frames, resize=transform.size, crop=transform.crop,
-                                   scale_255=transform.scale_255, layout=packed_layout)
+                                   scale_255=transform.scale_255, layout=model.packed_layout)
     else:
         even = st.frames[:-1] if st.on_device else st.frames
         if dev is not None and not even.is_cuda:
@@ -243,17 +276,18 @@ def staged_clip_logits(model, st: StagedVideo, transform: TestTransform, batch_c
     zi = frames.shape[0] - 1
     idx = torch.tensor([[(s // CLIP_STRIDE + k - st.f_lo) if (s + CLIP_STRIDE * k) < st.total else zi
                          for k in range(NUM_SEGMENTS)] for s in starts[st.lo:st.hi]], device=frames.device)
-    out = []
-    for b in range(0, idx.shape[0], batch_clips):
-        clips = frames[idx[b:b + batch_clips]]                                # [b, 8, 3, 224, 224] / packed
-        if hip_transform:       # device logits are collected and copied to the host once per video
-            out.append(model.forward_device(clips.contiguous(), layout=packed_layout))
-        elif dev is not None and hasattr(model, 'forward_device'):
-            out.append(model.forward_device(clips.contiguous()))
-        else:
-            name = model.get_inputs()[0].name
-            out.append(torch.from_numpy(np.asarray(model.run(None, {name: clips.cpu().numpy()})[0])))
-    return torch.cat(out, dim=0).to(torch.float32).cpu()
+    return frames, idx, hip_transform
+
+
+def _forward_clips(model, clips: torch.Tensor, hip_transform: bool) -> torch.Tensor:
+    """One batch of gathered clips ([b, 8, 3, 224, 224] float32, or [b, 8, ...packed] on the HIP path) -> logits
+    [b, num_class] (a device tensor on the engine paths: no host sync here)."""
+    if hip_transform:
+        return model.forward_device(clips.contiguous(), layout=model.packed_layout)
+    if _engine_device(model) is not None and hasattr(model, 'forward_device'):
+        return model.forward_device(clips.contiguous())
+    name = model.get_inputs()[0].name
+    return torch.from_numpy(np.asarray(model.run(None, {name: clips.cpu().numpy()})[0]))
 
 
 def video_clip_logits(model, video_thwc_u8: torch.Tensor, transform: TestTransform,
@@ -368,23 +402,144 @@ def _inference_dataset_by_videos(model, items: list, out_dir: str, checkpoint: s
                 _write_score_json(out_dir, items[r0 + r], checkpoint, every[r, :int(metas[r, 1])], int(metas[r, 0]))
 
 
+def estimated_clips(item, frame_counter: Optional[Callable[[str], int]] = None) -> int:
+    """Clip count of a video WITHOUT decoding it, for the shard plan only (the real frame count comes from the decoded
+    video): ``frame_counter(path)`` if given, the rawframes count of the annotation helper, the header of a ``.npy``
+    frame file, else the last annotated repetition frame (a lower bound)."""
+    frames = -1
+    if frame_counter is not None:
+        frames = int(frame_counter(item.video_path))
+    elif getattr(item, 'total_frames', -1) > 0:
+        frames = int(item.total_frames)
+    elif item.video_path.endswith('.npy') and os.path.exists(item.video_path):
+        frames = int(np.load(item.video_path, mmap_mode='r').shape[0])
+    if frames <= 0:
+        frames = max([int(r) for r in item.reps] + [CLIP_STEP])
+    return len(clip_starts(frames))
+
+
+class _ClipBatcher:
+    """Full ``batch_clips`` batches across video boundaries: clips of consecutive videos are queued and forwarded
+    whenever a whole batch is there (the ragged remainder once, at the end), and every logits row goes back to the
+    video it came from.  Clips are independent units (the temporal shift never leaves a clip) and the engine's
+    results do not depend on the batch a clip rides in, so this is bit-identical to per-video batches."""
+
+    def __init__(self, model, batch_clips: int):
+        self.model, self.batch = model, int(batch_clips)
+        self.queue: List[Tuple[int, torch.Tensor, bool]] = []     # (video key, clips [n, 8, ...], packed device format)
+        self.queued = 0
+        self.rows: Dict[int, List[torch.Tensor]] = {}
+
+    def add(self, key: int, frames: torch.Tensor, idx: torch.Tensor, hip_transform: bool) -> None:
+        self.rows.setdefault(key, [])
+        pos, n = 0, int(idx.shape[0])
+        while pos < n:
+            take = min(self.batch - self.queued, n - pos)
+            self.queue.append((key, frames[idx[pos:pos + take]], hip_transform))
+            self.queued += take
+            pos += take
+            if self.queued == self.batch:
+                self.flush()
+
+    def flush(self) -> None:
+        if not self.queue:
+            return
+        hip = self.queue[0][2]
+        assert all(q[2] == hip for q in self.queue)
+        clips = self.queue[0][1] if len(self.queue) == 1 else torch.cat([q[1] for q in self.queue], dim=0)
+        out = _forward_clips(self.model, clips, hip)
+        pos = 0
+        for key, part, _ in self.queue:
+            self.rows[key].append(out[pos:pos + part.shape[0]])
+            pos += part.shape[0]
+        self.queue, self.queued = [], 0
+
+    def logits(self, key: int) -> torch.Tensor:
+        parts = self.rows.pop(key)
+        return torch.cat(parts, dim=0) if parts else torch.empty((0, getattr(self.model, 'num_class', 0)))
+
+
+def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str, transform, reader, batch_clips: int,
+                              frame_counter: Optional[Callable[[str], int]] = None) -> None:
+    """``shard='global'``: the (video, clip) index of the whole job is laid out once -- whole videos, longest first,
+    each to the least-loaded rank (``distributed.plan_video_shards``) -- every rank then decodes and runs ITS videos
+    with full cross-video batches and NO collective inside the loop, and the job ends with one exchange: an
+    all-gather of the per-video [index, frames, clips] table and ONE padded all-gather of the per-clip logits
+    ``[clips_on_rank, num_class]``; rank 0 writes the JSON files in dataset order."""
+    rank, world = tdist.world_info()
+    dev = _engine_device(model)
+    counts = [estimated_clips(it, frame_counter) for it in items]
+    owner = tdist.plan_video_shards(counts, world)
+    mine = [v for v in range(len(items)) if owner[v] == rank]
+    batcher = _ClipBatcher(model, batch_clips)
+    meta = torch.full((len(items), 3), -1, dtype=torch.int64)      # rows of MY videos: [video index, frames, clips]
+    direct: Dict[int, torch.Tensor] = {}
+    staged = prefetch_staged(model, ((v, (lambda p=items[v].video_path: reader(p))) for v in mine))
+    for slot, (v, st) in enumerate(staged):
+        n_clips = st.hi - st.lo
+        meta[slot] = torch.tensor([v, st.total, n_clips])
+        if n_clips == 0:
+            batcher.rows.setdefault(v, [])
+        elif (not st.on_device and dev is not None and hasattr(model, 'packed_layout')
+                and int(st.frames.numel()) > MAX_STAGE_BYTES):
+            direct[v] = staged_clip_logits(model, st, transform, batch_clips)      # oversized: staged in pieces
+        else:
+            batcher.add(v, *_staged_clips(model, st, transform))
+    batcher.flush()
+    per_video = [direct[v] if v in direct else batcher.logits(v) for v in mine]
+    num_class = getattr(model, 'num_class', None) or (int(per_video[0].shape[1]) if per_video else 0)
+    local = (torch.cat([t.to(torch.float32).reshape(-1, num_class).cpu() for t in per_video], dim=0) if per_video
+             else torch.empty((0, num_class), dtype=torch.float32))      # one D2H per rank, after its last forward
+    if not tdist.collective_enabled():
+        pos = 0
+        for slot, v in enumerate(mine):
+            n = int(meta[slot, 2])
+            _write_score_json(out_dir, items[v], checkpoint, local[pos:pos + n], int(meta[slot, 1]))
+            pos += n
+        return
+    on_gpu = dev is not None and tdist.on_rccl()
+    metas = tdist.all_gather_logits(meta.to(dev) if on_gpu else meta).cpu().reshape(world, len(items), 3)
+    per = max(1, int(metas[:, :, 2].clamp(min=0).sum(dim=1).max()))
+    ncls = torch.tensor([[num_class]], dtype=torch.int64)
+    ncls = int(tdist.all_gather_logits(ncls.to(dev) if on_gpu else ncls).max()) if num_class == 0 else num_class
+    pad = torch.zeros((per, ncls), dtype=torch.float32)
+    pad[:local.shape[0]] = local.reshape(local.shape[0], ncls)
+    every = tdist.all_gather_logits(pad.to(dev) if on_gpu else pad).cpu().reshape(world, per, ncls)
+    if rank == 0:
+        where = {}
+        for r in range(world):
+            pos = 0
+            for v, frames, n in metas[r].tolist():
+                if v >= 0:
+                    where[v] = (r, pos, n, frames)
+                    pos += n
+        assert sorted(where) == list(range(len(items))), 'every video must come back from exactly one rank'
+        for v, item in enumerate(items):
+            r, pos, n, frames = where[v]
+            _write_score_json(out_dir, item, checkpoint, every[r, pos:pos + n], frames)
+
+
 def inference_dataset(model, splits: List[str], out_dir: str, checkpoint: str, person_crop: bool = False,
                       data_root: Optional[str] = None, anno_path: Optional[str] = None,
                       video_reader: Optional[Callable[[str], torch.Tensor]] = None, action: Sequence[str] = ('all',),
-                      batch_clips: int = 32, scale_255: bool = False, shard: Optional[str] = None) -> None:
+                      batch_clips: int = 32, scale_255: bool = False, shard: Optional[str] = None,
+                      frame_counter: Optional[Callable[[str], int]] = None) -> None:
     """Inference the RepCount dataset; one ``{video_name}.score.json`` per video with the reference's
     schema: video_name, model, input_shape, checkpoint, total_frames, ground_truth, action, scores.
 
-    Under ``torch.distributed``: ``shard='clips'`` splits the clips of every video over the ranks (one all-gather per
-    video; lowest latency per video, but every rank reads every video), ``shard='videos'`` gives whole videos to ranks
-    round-robin (each video is decoded once; full-size batches; two small all-gathers per W videos).  Default:
-    ``'videos'`` when there is more than one rank (the dataset-throughput form), ``'clips'`` otherwise; ask for
-    ``'clips'`` explicitly for the lowest latency on a single stream."""
+    Under ``torch.distributed``: ``shard='global'`` (the default with more than one rank: the dataset-throughput form,
+    SURVEY 8e "global clip index over a batch of videos ... gather once per many videos") assigns whole videos to
+    ranks by clip count, longest first, runs full cross-video batches with no collective inside the loop and
+    exchanges once at the end (``frame_counter(path) -> frames`` feeds the plan when neither rawframes nor ``.npy``
+    headers can; without it the annotation's last repetition frame does); ``shard='clips'`` splits the clips of
+    every video over the ranks (one all-gather per video: lowest latency for ONE stream, but every rank reads every
+    video); ``shard='videos'`` is the round-2 form, whole videos round-robin with an exchange per round of W videos
+    (each round lasts as long as its longest video)."""
     rank, _world = tdist.world_info()
     if shard is None:
-        shard = 'videos' if _world > 1 else 'clips'
-    if shard not in ('clips', 'videos'):
-        raise ValueError("shard must be 'clips' or 'videos'")
+        shard = 'global' if _world > 1 else 'clips'
+    if shard not in ('clips', 'videos', 'global'):
+        raise ValueError("shard must be 'clips', 'videos' or 'global'")
     if rank == 0 and not os.path.exists(out_dir):
         os.makedirs(out_dir)
     data_root = osp.expanduser(data_root or '~/data/RepCount/')
@@ -396,6 +551,10 @@ def inference_dataset(model, splits: List[str], out_dir: str, checkpoint: str, p
         print('==> transform:', transform)
     if shard == 'videos':
         _inference_dataset_by_videos(model, list(data.values()), out_dir, checkpoint, transform, reader, batch_clips)
+        return
+    if shard == 'global':
+        _inference_dataset_global(model, list(data.values()), out_dir, checkpoint, transform, reader, batch_clips,
+                                  frame_counter)
         return
     # Video i+1 is read, sliced, pinned and copied to the GPU by a worker thread while video i computes.
     videos = ((item, (lambda p=item.video_path: reader(p))) for item in data.values())
