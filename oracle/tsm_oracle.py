@@ -16,6 +16,8 @@ What each function follows in /root/reference (read as text, never imported):
   resnet50 trunk      torchvision 0.13.0 ResNet/Bottleneck (v1.5: stride on conv2, bias-free
                       convs, BN eps 1e-5, maxpool k3 s2 p1), kept by tsm.py:250-251,264-281
   head                workoutdetector/models/tsm.py:409-419 (+ SegmentConsensus :165-174)
+  tsm_forward_bf16    the same forward (tsm.py:409-419) with bf16 storage of weights / activations and fp32
+                      accumulation written out: the oracle of BASELINE config 5 ("bf16 weights")
 """
 from __future__ import annotations
 
@@ -131,6 +133,83 @@ def conv_bn_act(x: torch.Tensor, w: torch.Tensor, bn: Tuple[torch.Tensor, ...], 
     if residual is not None:
         h = h + residual
     return F.relu(h) if relu else h
+
+
+# ---- bf16-storage restatement (BASELINE config 5) ----------------------------------------------------------------
+# The same graph (tsm.py:409-419) with the roundings of a bf16-storage deployment written out: BatchNorm folded into
+# the conv in fp32 (scale = gamma / sqrt(var + eps), w * scale, bias = beta - mean * scale), the folded weights and
+# EVERY stored activation rounded to bfloat16 (round to nearest even), every sum accumulated in fp32.  A block's
+# conv3 and its downsample branch accumulate into ONE fp32 sum before the single rounding of the block output (that
+# is what "store once" means for the first block of a stage); the classifier reads the stored bf16 features and
+# works in fp32.  Against THIS oracle the bf16 engine's error is fp32 accumulation order plus the rare rounding
+# boundary flip, not the 2^-9 per layer of the format itself -- so the bar can be two orders tighter than against
+# the fp32 oracle, and a dropped K-tile or a wrong residual source no longer hides under the format's own error.
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> nearest-even bfloat16 -> fp32."""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def fold_bn(w: torch.Tensor, bn: Tuple[torch.Tensor, ...]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(w * gamma / sqrt(var + eps), beta - mean * gamma / sqrt(var + eps)), all fp32."""
+    g, b, m, v = (t.to(torch.float32) for t in bn)
+    scale = g / torch.sqrt(v + torch.tensor(BN_EPS, dtype=torch.float32))
+    return w.to(torch.float32) * scale[:, None, None, None], b - m * scale
+
+
+def _sd_bn(sd: Dict[str, torch.Tensor], prefix: str) -> Tuple[torch.Tensor, ...]:
+    return (sd[prefix + '.weight'], sd[prefix + '.bias'], sd[prefix + '.running_mean'], sd[prefix + '.running_var'])
+
+
+def conv_bn_act_bf16(x: torch.Tensor, w: torch.Tensor, bn: Tuple[torch.Tensor, ...], stride: int, padding: int,
+                     relu: bool, residual: Optional[torch.Tensor] = None, round_output: bool = False) -> torch.Tensor:
+    """Per-op oracle of a bf16-storage conv: operands (input, folded weights, residual) rounded to bf16, fp32
+    accumulate, fp32 bias; the result is left UNROUNDED by default so that a test can ask "is the kernel's bf16 output
+    a correct rounding of this value" (|got - want| <= 2^-8 |want|) without tripping over boundary flips."""
+    wf, bias = fold_bn(w, bn)
+    h = F.conv2d(bf16_round(x), bf16_round(wf), stride=stride, padding=padding) + bias[None, :, None, None]
+    if residual is not None:
+        h = h + bf16_round(residual)
+    h = F.relu(h) if relu else h
+    return bf16_round(h) if round_output else h
+
+
+def _bottleneck_bf16(x: torch.Tensor, sd: Dict[str, torch.Tensor], prefix: str, stride: int, n_segment: int,
+                     shift_div: int, is_shift: bool) -> torch.Tensor:
+    h = temporal_shift(x, n_segment, shift_div) if is_shift else x
+    h = conv_bn_act_bf16(h, sd[_conv1_key(sd, prefix)], _sd_bn(sd, prefix + '.bn1'), 1, 0, True, round_output=True)
+    h = conv_bn_act_bf16(h, sd[prefix + '.conv2.weight'], _sd_bn(sd, prefix + '.bn2'), stride, 1, True, round_output=True)
+    w3, b3 = fold_bn(sd[prefix + '.conv3.weight'], _sd_bn(sd, prefix + '.bn3'))
+    out = F.conv2d(h, bf16_round(w3))
+    if prefix + '.downsample.0.weight' in sd:
+        wd, bd = fold_bn(sd[prefix + '.downsample.0.weight'], _sd_bn(sd, prefix + '.downsample.1'))
+        out = out + F.conv2d(x, bf16_round(wd), stride=stride) + (b3 + bd)[None, :, None, None]
+    else:
+        out = out + b3[None, :, None, None] + x
+    return bf16_round(F.relu(out))
+
+
+@torch.no_grad()
+def tsm_forward_bf16(sd: Dict[str, torch.Tensor], x: torch.Tensor, n_segment: int = 8, shift_div: int = 8,
+                     is_shift: bool = True, taps: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """``tsm_forward`` with bf16 storage of weights and activations, fp32 accumulation (see the block comment above)."""
+    if x.dim() == 5:
+        x = x.reshape((-1,) + tuple(x.shape[2:]))
+    assert x.dim() == 4 and x.shape[1] == 3 and x.shape[0] % n_segment == 0
+    h = conv_bn_act_bf16(x.to(torch.float32), sd['base_model.conv1.weight'], _sd_bn(sd, 'base_model.bn1'), 2, 3, True,
+                         round_output=True)
+    h = F.max_pool2d(h, kernel_size=3, stride=2, padding=1)
+    if taps is not None:
+        taps['stem'] = h
+    for li, nblocks in enumerate(R50_BLOCKS, start=1):
+        for b in range(nblocks):
+            stride = 2 if (b == 0 and li > 1) else 1
+            h = _bottleneck_bf16(h, sd, f'base_model.layer{li}.{b}', stride, n_segment, shift_div, is_shift)
+            if taps is not None:
+                taps[f'layer{li}.{b}'] = h
+    out = head(h, sd, n_segment)
+    if taps is not None:
+        taps['logits'] = out
+    return out
 
 
 def layer_table(height: int = 224, width: int = 224) -> List[dict]:

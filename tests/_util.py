@@ -24,6 +24,33 @@ def assert_close(got, want, rtol, atol_scale=1e-4, what=''):
     return float(err.max() / (scale + 1e-30))
 
 
+BF16_OP_RTOL = 2.0 ** -8      # half a bf16 ulp (8 significand bits) relative to the value: 3.9e-3
+BF16_E2E_BAR = 1e-2           # logits of the bf16 engine vs the bf16-storage oracle, fraction of the logit scale
+
+
+def assert_bf16_op(got, want_unrounded, what='', atol_scale=2e-5):
+    """A bf16-storage kernel's output against the bf16 oracle's UNROUNDED fp32 result (operands rounded exactly as the
+    kernel rounds them, fp32 accumulate): the stored value must be a correct rounding of it -- within half a bf16 ulp
+    (rtol 2^-8 <= 4e-3) plus the fp32 accumulation-order noise (atol_scale of the tensor's scale)."""
+    return assert_close(got, want_unrounded, rtol=BF16_OP_RTOL, atol_scale=atol_scale, what=what)
+
+
+def bf16_logits_report(got, want_bf16, want_f32, what, capsys=None):
+    """The bf16 engine's logits: asserted against the bf16-storage oracle (BF16_E2E_BAR of the scale, same arg-max),
+    REPORTED against the fp32 oracle (the accuracy figure of the mode, not a parity bar)."""
+    got, want_bf16, want_f32 = (np.asarray(a, dtype=np.float64) for a in (got, want_bf16, want_f32))
+    scale = float(np.abs(want_f32).max())
+    e_model = float(np.abs(got - want_bf16).max()) / scale
+    e_f32 = float(np.abs(got - want_f32).max()) / scale
+    msg = f'[{what}] logits max|err|/scale: {e_model:.3g} vs the bf16-storage oracle (bar {BF16_E2E_BAR:g}), {e_f32:.3g} vs the fp32 oracle'
+    if capsys is not None:
+        with capsys.disabled():
+            print('\n' + msg)
+    assert np.isfinite(got).all() and e_model <= BF16_E2E_BAR, msg
+    assert (got.argmax(1) == want_bf16.argmax(1)).all(), msg
+    return e_model, e_f32
+
+
 def fit_probe_fc(sd, video_u8, num_class=12, on=4, off=5, gain=8.0):
     """Classifier for the seeded trunk that separates bright from dark clips of a synthetic stream, so
     that random-init weights give alternating start/end states (classes ``on``/``off``) and a

@@ -1,14 +1,17 @@
 """TSM_DTYPE_BF16 (BASELINE.json config 5: bf16 weights + activations, fp32 accumulate).
 
 This mode is NOT claimed to meet fp32 rtol 1e-3: every activation is rounded to 8 significand bits once per
-layer.  Tolerances used here (and measured errors printed with -s): per conv op 2e-2 of the output scale;
-logits after 53 conv layers 5e-2 of the logit scale."""
+layer.  Its parity oracle is therefore the bf16-STORAGE restatement (oracle/tsm_oracle.py::tsm_forward_bf16,
+conv_bn_act_bf16: weights after the BN fold and every stored activation rounded exactly where the engine rounds, fp32
+accumulate): per conv op the stored value must be a correct bf16 rounding of the oracle's fp32 result (rtol 2^-8 =
+3.9e-3, tests/_util.py::assert_bf16_op), logits within 1e-2 of the logit scale with the same arg-max.  The distance
+to the fp32 oracle is printed (-s) as the mode's accuracy figure, not asserted as parity."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import tsm_oracle
-from tests._util import assert_close, make_input
+from tests._util import assert_bf16_op, assert_close, bf16_logits_report, make_input
 from tests.test_ops_gpu import CONV_CASES, _bn, _nchw, _nhwc
 
 pytestmark = pytest.mark.gpu
@@ -27,11 +30,11 @@ def test_conv_bn_act_bf16(hip_lib, n, hi, wi, cin, cout, k, stride, relu, use_re
     ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
     res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
     xin = tsm_oracle.temporal_shift(x, shiftT, 8) if shiftT else x
-    want = tsm_oracle.conv_bn_act(xin, w, bn, stride, pad, relu, res)
+    want = tsm_oracle.conv_bn_act_bf16(xin, w, bn, stride, pad, relu, res)
     got = conv_bn_act_nhwc(_nhwc(x).cuda(), w.cuda(), *[b.cuda() for b in bn], stride=stride, relu=relu,
                            residual=None if res is None else _nhwc(res).cuda(), shift_segments=shiftT, fold_div=8,
                            dtype='bf16')
-    assert_close(_nchw(got.cpu()).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='conv bf16')
+    assert_bf16_op(_nchw(got.cpu()).numpy(), want.numpy(), what='conv bf16')
 
 
 def test_config5_shape_t16_256(hip_lib, sd0, capsys):
@@ -39,18 +42,14 @@ def test_config5_shape_t16_256(hip_lib, sd0, capsys):
     from workoutdetector_amd.engine import TsmEngine
     x = make_input(55, 2, 16, 256, 256)
     want = tsm_oracle.tsm_forward(sd0, torch.from_numpy(x), n_segment=16).numpy()
-    scale = float(np.abs(want).max())
+    want_bf16 = tsm_oracle.tsm_forward_bf16(sd0, torch.from_numpy(x), n_segment=16).numpy()
     eng = TsmEngine(num_segments=16, height=256, width=256, max_clips=2, state_dict=sd0, dtype='bf16')
     got = eng.run(None, {'input': x})[0]
     eng.close()
-    err = float(np.abs(got - want).max())
-    with capsys.disabled():
-        print(f'\n[bf16 T=16 256^2] logits max|err| = {err:.4g} at scale {scale:.4g} ({err / scale:.3g} relative)')
-    assert err <= 5e-2 * scale
-    assert (got.argmax(1) == want.argmax(1)).all()
+    bf16_logits_report(got, want_bf16, want, 'bf16 T=16 256^2', capsys)
     # the same shape in the exact-fp32 engine meets the fp32 bar
     f32 = TsmEngine(num_segments=16, height=256, width=256, max_clips=2, state_dict=sd0)
-    assert_close(f32.run(None, {'input': x})[0], want, rtol=1e-3, atol_scale=1e-4, what='f32 T=16 256^2')
+    assert_close(f32.run(None, {'input': x})[0], want, rtol=1e-3, atol_scale=1e-5, what='f32 T=16 256^2')
     f32.close()
 
 
@@ -62,15 +61,19 @@ def test_bf16_engine_224_taps_and_packed_input(hip_lib, sd0, capsys):
     eng = TsmEngine(max_clips=2, state_dict=sd0, dtype='bf16')
     x = make_input(100, 2, 8, 224, 224)
     taps = {}
-    want = tsm_oracle.tsm_forward(sd0, torch.from_numpy(x), taps=taps).numpy()
+    want = tsm_oracle.tsm_forward(sd0, torch.from_numpy(x)).numpy()
+    want_bf16 = tsm_oracle.tsm_forward_bf16(sd0, torch.from_numpy(x), taps=taps).numpy()
     got = eng.run(None, {'input': x})[0]
-    scale = float(np.abs(want).max())
-    with capsys.disabled():
-        print(f'\n[bf16 224] logits max|err|/scale = {float(np.abs(got - want).max()) / scale:.3g}')
-    assert float(np.abs(got - want).max()) <= 5e-2 * scale
-    for stage in ['stem', 'layer1.0', 'layer2.0']:
+    bf16_logits_report(got, want_bf16, want, 'bf16 224', capsys)
+    # stage taps against the bf16-storage oracle: the stem must agree to a rounding (one conv deep); deeper taps carry
+    # the rare boundary flips of the layers before them, each worth one bf16 ulp of one element, diluted by the next K
+    for stage, frac in [('stem', 0.0), ('layer1.0', 2e-3), ('layer2.0', 2e-3), ('layer3.0', 2e-3), ('layer4.2', 2e-3)]:
         t = taps[stage].permute(0, 2, 3, 1).numpy()
-        assert float(np.abs(eng.forward_tap(x, stage) - t).max()) <= 3e-2 * float(np.abs(t).max()), stage
+        g = eng.forward_tap(x, stage)
+        bad = np.abs(g - t) > 2.0 ** -7 * np.abs(t) + 1e-5 * float(np.abs(t).max())     # more than one bf16 ulp apart
+        with capsys.disabled():
+            print(f'[bf16 224] {stage}: {int(bad.sum())} of {bad.size} elements more than one bf16 ulp from the bf16-storage oracle')
+        assert bad.mean() <= frac, (stage, float(bad.mean()))
     vid = torch.from_numpy(synthetic_video(3, 16, 120, 90))
     packed = preprocess_frames(vid.cuda(), layout=eng.packed_layout, scale_255=True)
     assert eng.packed_layout == _lib.LAYOUT_NTHWC8B and tuple(packed.shape) == (16, 224, 112, 4)
@@ -179,8 +182,8 @@ def test_lds_dma_256_tile_equals_the_128_tiles_bitwise(hip_lib, monkeypatch, n, 
                                       shift_segments=shiftT, fold_div=8, dtype='bf16').cpu()
     assert torch.equal(outs['256x256'], outs['128x128']) and torch.equal(outs['256x256'], outs['64x64'])
     xin = tsm_oracle.temporal_shift(x, shiftT, 8) if shiftT else x
-    want = tsm_oracle.conv_bn_act(xin, w, bn, stride, k // 2, relu, res)
-    assert_close(_nchw(outs['256x256']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='256x256 bf16')
+    want = tsm_oracle.conv_bn_act_bf16(xin, w, bn, stride, k // 2, relu, res)
+    assert_bf16_op(_nchw(outs['256x256']).numpy(), want.numpy(), what='256x256 bf16')
 
 
 @pytest.mark.parametrize('ch,n,hi,wi,relu', [
@@ -217,8 +220,8 @@ def test_weight_stationary_3x3_equals_the_igemm_tiles_bitwise(hip_lib, monkeypat
     assert torch.equal(outs['64x64'], outs['128x64'])
     assert torch.equal(outs['ws'], outs['64x64'])
     if n * hi * wi <= 70000:
-        want = tsm_oracle.conv_bn_act(x, w, bn, 1, 1, relu, None)
-        assert_close(_nchw(outs['ws']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='ws bf16')
+        want = tsm_oracle.conv_bn_act_bf16(x, w, bn, 1, 1, relu, None)
+        assert_bf16_op(_nchw(outs['ws']).numpy(), want.numpy(), what='ws bf16')
 
 
 @pytest.mark.parametrize('cin,n,hi,wi,shiftT,relu', [
@@ -247,8 +250,8 @@ def test_weight_stationary_1x1_equals_the_igemm_tiles_bitwise(hip_lib, monkeypat
     assert torch.equal(outs['64x64'], outs['128x64'])
     assert torch.equal(outs['ws'], outs['64x64'])
     xin = tsm_oracle.temporal_shift(x, shiftT, 8) if shiftT else x
-    want = tsm_oracle.conv_bn_act(xin, w, bn, 1, 0, relu, None)
-    assert_close(_nchw(outs['ws']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='ws 1x1 bf16')
+    want = tsm_oracle.conv_bn_act_bf16(xin, w, bn, 1, 0, relu, None)
+    assert_bf16_op(_nchw(outs['ws']).numpy(), want.numpy(), what='ws 1x1 bf16')
 
 
 @pytest.mark.parametrize('cin,cout,n,hi,wi,shiftT,relu', [
@@ -276,8 +279,8 @@ def test_weight_stationary_1x1_wide_equals_the_igemm_tiles_bitwise(hip_lib, monk
     assert torch.equal(outs['64x64'], outs['128x128'])
     assert torch.equal(outs['ws'], outs['64x64'])
     xin = tsm_oracle.temporal_shift(x, shiftT, 8) if shiftT else x
-    want = tsm_oracle.conv_bn_act(xin, w, bn, 1, 0, relu, None)
-    assert_close(_nchw(outs['ws']).numpy(), want.numpy(), rtol=2e-2, atol_scale=2e-2, what='wsn 1x1 bf16')
+    want = tsm_oracle.conv_bn_act_bf16(xin, w, bn, 1, 0, relu, None)
+    assert_bf16_op(_nchw(outs['ws']).numpy(), want.numpy(), what='wsn 1x1 bf16')
 
 
 @pytest.mark.parametrize('h,w,b', [(256, 256, 2), (224, 224, 2), (90, 70, 3)])

@@ -1,7 +1,8 @@
 """End-to-end parity of the HIP engine (through the C ABI) against the CPU oracle.
 
 Tolerance (BASELINE.json north_star): fp32 rtol 1e-3 on logits; written here as
-|hip - oracle| <= 1e-3*|oracle| + 1e-4*max|oracle|.
+|hip - oracle| <= 1e-3*|oracle| + 1e-5*max|oracle| (the absolute term only keeps logits that happen to sit near zero
+from demanding more than fp32 has; measured error: 3e-7 of the scale in f32, 5e-6 in bf16x3).
 """
 import json
 
@@ -28,7 +29,7 @@ def test_logits_parity_224(engine224, sd0):
     want = tsm_oracle.tsm_forward(sd0, torch.from_numpy(x)).numpy()
     got = engine224.run(None, {engine224.get_inputs()[0].name: x})[0]
     assert got.shape == (2, 12) and got.dtype == np.float32
-    assert_close(got, want, rtol=1e-3, atol_scale=1e-4, what='logits 224')
+    assert_close(got, want, rtol=1e-3, atol_scale=1e-5, what='logits 224')
 
 
 def test_stage_taps_224(engine224, sd0):
@@ -40,7 +41,7 @@ def test_stage_taps_224(engine224, sd0):
                   'layer4.2']:
         got = engine224.forward_tap(x, stage)
         want = taps[stage].permute(0, 2, 3, 1).numpy()
-        assert_close(got, want, rtol=1e-3, atol_scale=1e-4, what=stage)
+        assert_close(got, want, rtol=1e-3, atol_scale=1e-5, what=stage)
 
 
 def test_golden_logits(hip_lib, golden_dir):
@@ -54,7 +55,7 @@ def test_golden_logits(hip_lib, golden_dir):
                         state_dict=make_state_dict(case['weight_seed'], 12))
         x = make_input(case['input_seed'], b, t, h, w)
         got = eng.run(None, {'input': x})[0]
-        assert_close(got, np.array(case['logits'], dtype=np.float32), rtol=1e-3, atol_scale=1e-4, what=name)
+        assert_close(got, np.array(case['logits'], dtype=np.float32), rtol=1e-3, atol_scale=1e-5, what=name)
         eng.close()
 
 
@@ -86,7 +87,7 @@ def test_no_shift_engine(hip_lib, sd0):
     eng = TsmEngine(num_class=12, num_segments=8, height=64, width=64, max_clips=2, is_shift=False, state_dict=sd0)
     x = make_input(5, 2, 8, 64, 64)
     want = tsm_oracle.tsm_forward(sd0, torch.from_numpy(x), is_shift=False).numpy()
-    assert_close(eng.run(None, {'input': x})[0], want, rtol=1e-3, atol_scale=1e-4, what='no-shift')
+    assert_close(eng.run(None, {'input': x})[0], want, rtol=1e-3, atol_scale=1e-5, what='no-shift')
     eng.close()
 
 
@@ -160,22 +161,32 @@ def test_create_model_from_checkpoint_and_onnx(hip_lib, sd0, tmp_path):
     ref = TsmEngine(height=64, width=64, max_clips=1, state_dict=sd0)
     want = ref.run(None, {'input': x})[0]
     ref.close()
+    # the oracle leg: every imported weight source is also held against the CPU oracle on the ORIGINAL state dict
+    # (an import that permuted or dropped a tensor identically for all four sources would still agree engine-to-engine)
+    oracle_want = tsm_oracle.tsm_forward(sd0, torch.from_numpy(x)).numpy()
+    assert_close(want, oracle_want, rtol=1e-3, atol_scale=1e-5, what='state dict vs oracle')
     keys = list(sd0)
     ck = {'state_dict': {('module.' + k).replace('module.fc.', 'module.new_fc.'): sd0[k] for k in keys}}
     torch.save(ck, tmp_path / 'tsm.pth')
     m = create_model(num_class=12, checkpoint=str(tmp_path / 'tsm.pth'), device='cuda:0', height=64, width=64, max_clips=1)
-    assert np.array_equal(m.run(None, {'input': x})[0], want)
+    got = m.run(None, {'input': x})[0]
+    assert np.array_equal(got, want)
+    assert_close(got, oracle_want, rtol=1e-3, atol_scale=1e-5, what='.pth checkpoint vs oracle')
     m.close()
     from tests.test_weights import _to_mmaction          # mmaction2 checkpoint of the reference's --mmlab branch
     torch.save({'meta': {}, 'state_dict': _to_mmaction(sd0)}, tmp_path / 'tsm_mmaction.pth')
     m = create_model(num_class=12, checkpoint=str(tmp_path / 'tsm_mmaction.pth'), device='cuda:0', height=64, width=64,
                      max_clips=1)
-    assert np.array_equal(m.run(None, {'input': x})[0], want)
+    got = m.run(None, {'input': x})[0]
+    assert np.array_equal(got, want)
+    assert_close(got, oracle_want, rtol=1e-3, atol_scale=1e-5, what='mmaction checkpoint vs oracle')
     m.close()
     export_onnx(LitWrapper(TorchTSM(num_class=12).load_engine_state_dict(sd0)), str(tmp_path / 'tsm.onnx'),
                 sample_shape=(1, 8, 3, 64, 64))
     m = create_model(num_class=12, checkpoint=str(tmp_path / 'tsm.onnx'), device='cuda:0', height=64, width=64, max_clips=1)
-    assert_close(m.run(None, {'input': x})[0], want, rtol=1e-5, atol_scale=1e-6, what='onnx-imported weights')
+    got = m.run(None, {'input': x})[0]
+    assert_close(got, want, rtol=1e-5, atol_scale=1e-6, what='onnx-imported weights')
+    assert_close(got, oracle_want, rtol=1e-3, atol_scale=1e-5, what='onnx-imported weights vs oracle')
     m.close()
 
 
@@ -194,19 +205,19 @@ def test_c_program_runs_a_forward(hip_lib, tmp_path):
     ('f32', 3, 8, 64, 96, 2, 1e-3),          # odd segment count (the reference's factory default num_class=2)
     ('f32', 1, 8, 64, 64, 12, 1e-3),         # single-frame clips: both shifted channel groups read zeros
     ('bf16x3', 4, 8, 96, 64, 7, 1e-3),
-    ('bf16', 2, 8, 64, 64, 12, 5e-2),
+    ('bf16', 2, 8, 64, 64, 12, 1e-2),
     ('f32', 2, 8, 270, 480, 12, 1e-3),       # wide frames: many pooled tiles per row, ragged in both directions
     ('bf16x3', 2, 8, 270, 480, 12, 1e-3),
     # the round-2 kernels forced on (the tuner would otherwise decide by timing): fused conv2 + conv3, 256 x 256 LDS-DMA tile
     ('f32+fused', 3, 8, 64, 96, 2, 1e-3),
     ('f32+fused', 4, 16, 96, 128, 5, 1e-3),
     ('bf16x3+fused', 4, 8, 96, 64, 7, 1e-3),
-    ('bf16+fused', 4, 8, 96, 64, 7, 5e-2),
-    ('bf16+fused', 3, 8, 90, 70, 12, 5e-2),
-    ('bf16+256x256', 2, 8, 64, 64, 12, 5e-2),
-    ('bf16+256x256', 3, 8, 90, 70, 12, 5e-2),
+    ('bf16+fused', 4, 8, 96, 64, 7, 1e-2),
+    ('bf16+fused', 3, 8, 90, 70, 12, 1e-2),
+    ('bf16+256x256', 2, 8, 64, 64, 12, 1e-2),
+    ('bf16+256x256', 3, 8, 90, 70, 12, 1e-2),
 ])
-def test_unusual_configurations_against_oracle(hip_lib, monkeypatch, dtype, t, div, h, w, ncls, rtol):
+def test_unusual_configurations_against_oracle(hip_lib, monkeypatch, capsys, dtype, t, div, h, w, ncls, rtol):
     """Segment counts, shift_div, class counts and aspect ratios other than the headline's, vs the CPU oracle."""
     from workoutdetector_amd.engine import TsmEngine
     from workoutdetector_amd.weights import make_state_dict, to_torch
@@ -224,7 +235,13 @@ def test_unusual_configurations_against_oracle(hip_lib, monkeypatch, dtype, t, d
     eng.close()
     want = tsm_oracle.tsm_forward(to_torch(sd), torch.from_numpy(x), n_segment=t, shift_div=div).numpy()
     assert got.shape == (3, ncls)
-    assert_close(got, want, rtol=rtol, atol_scale=rtol / 10, what=f'{dtype} T={t} div={div} {h}x{w}')
+    if dtype == 'bf16':      # its own oracle: the bf16-storage restatement (bar = 1e-2 of the logit scale, same arg-max)
+        from tests._util import BF16_E2E_BAR, bf16_logits_report
+        assert rtol == BF16_E2E_BAR
+        want_bf16 = tsm_oracle.tsm_forward_bf16(to_torch(sd), torch.from_numpy(x), n_segment=t, shift_div=div).numpy()
+        bf16_logits_report(got, want_bf16, want, f'bf16 T={t} div={div} {h}x{w}', capsys)
+        return
+    assert_close(got, want, rtol=rtol, atol_scale=1e-5, what=f'{dtype} T={t} div={div} {h}x{w}')
 
 
 def test_split_k_is_bitwise_identical_to_whole_k(hip_lib, sd0, monkeypatch):

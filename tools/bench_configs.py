@@ -209,7 +209,7 @@ def config4_scaling(args):
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
         ic.inference_dataset(eng, ['val'], os.path.join(root, 'out'), checkpoint='seed0', data_root=root,
-                             video_reader=reader, frame_counter=counter, batch_clips=32)
+                             video_reader=reader, frame_counter=counter, batch_clips=32, shard='global')
     sync()
     dt = torch.tensor([time.perf_counter() - t0], device='cuda')
     if world > 1:
