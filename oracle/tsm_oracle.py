@@ -150,10 +150,15 @@ def bf16_round(x: torch.Tensor) -> torch.Tensor:
 
 
 def fold_bn(w: torch.Tensor, bn: Tuple[torch.Tensor, ...]) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(w * gamma / sqrt(var + eps), beta - mean * gamma / sqrt(var + eps)), all fp32."""
-    g, b, m, v = (t.to(torch.float32) for t in bn)
-    scale = g / torch.sqrt(v + torch.tensor(BN_EPS, dtype=torch.float32))
-    return w.to(torch.float32) * scale[:, None, None, None], b - m * scale
+    """(w * gamma / sqrt(var + eps), beta - mean * gamma / sqrt(var + eps)), every operation a correctly rounded fp32
+    one.  Done in numpy: torch's vectorised CPU ``sqrt`` is 1 ulp off for about 1 % of inputs, and one ulp of the
+    folded weight is enough to flip its bf16 rounding (0.4 % of that weight) -- the fold has to be reproducible to
+    the bit for a bf16-storage oracle to mean anything."""
+    import numpy as np
+    g, b, m, v = (t.detach().to(torch.float32).numpy() for t in bn)
+    scale = (g / np.sqrt(v + np.float32(BN_EPS))).astype(np.float32)
+    wf = w.detach().to(torch.float32).numpy() * scale[:, None, None, None]
+    return torch.from_numpy(wf.astype(np.float32)), torch.from_numpy((b - m * scale).astype(np.float32))
 
 
 def _sd_bn(sd: Dict[str, torch.Tensor], prefix: str) -> Tuple[torch.Tensor, ...]:

@@ -1,0 +1,91 @@
+"""Resource budgets of the built gfx950 code object: registers, LDS, scratch and the occupancy figures
+DESIGN.md quotes are read from libtsm_hip.so's own metadata (workoutdetector_amd/codeobj.py) and asserted here, on the CPU.
+Several kernels sit right at a budget; a compiler bump that spills inside a K loop or drops a resident workgroup must
+fail a test, not show up as an unexplained benchmark regression."""
+import pytest
+
+from workoutdetector_amd import codeobj
+from workoutdetector_amd.build import build_library
+
+
+@pytest.fixture(scope='module')
+def md():
+    return codeobj.kernel_metadata(build_library())
+
+
+def _one(md, name):
+    assert name in md, f'{name} not in the code object; kernels: {sorted(md)[:8]}...'
+    return md[name]
+
+
+def test_every_kernel_is_there_and_wave64(md):
+    assert len(md) >= 100
+    for name, r in md.items():
+        assert r['.wavefront_size'] == 64, name
+        assert not r['.uses_dynamic_stack'], name
+        assert r['.vgpr_count'] <= codeobj.SIMD_VGPRS, name
+
+
+def test_no_scratch_anywhere_but_the_two_known_prologue_spills(md):
+    """Scratch in a K loop is a 10x slowdown.  The only kernels allowed any are the two segmented fp32 64x64 tiles, which
+    trade 1-2 registers spilled OUTSIDE the K loop (8-12 bytes) for the 96-register budget of 5 waves per SIMD (DESIGN
+    4.1); everything else -- every MFMA loop of every mode -- must be scratch-free."""
+    allowed = {'conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, true>': 16,
+               'conv_igemm<64, 64, 2, 2, 1, true, false, 0, false, true>': 16}
+    for name, r in md.items():
+        limit = allowed.get(name, 0)
+        assert r['.private_segment_fixed_size'] <= limit, (name, r['.private_segment_fixed_size'])
+        assert r['.vgpr_spill_count'] <= limit // 4, (name, r['.vgpr_spill_count'])     # (SGPRs spill to VGPR lanes, not memory)
+
+
+def test_fp32_headline_kernel_keeps_five_workgroups_per_cu(md):
+    """The dominant kernel of the headline (3x3 convs of layer2-4, segmented K, register-resident K-step): 18 KB of LDS
+    and <= 102 registers -> 5 workgroups of 4 waves per CU = 5 waves per SIMD."""
+    for name in ('conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, true>',       # 3x3
+                 'conv_igemm<64, 64, 2, 2, 1, true, false, 0, false, true>',        # shifted conv1, long K
+                 'conv_igemm<64, 64, 2, 2, 1, false, false, 0, true, true>'):       # conv3 + downsample of layer4.0
+        r = _one(md, name)
+        assert r['.group_segment_fixed_size'] == 18432 and r['.max_flat_workgroup_size'] == 256
+        assert r['waves_per_simd'] >= 5 and r['workgroups_per_cu'] >= 5, (name, r['.vgpr_count'])
+
+
+def test_fused_conv23_kernels_keep_sixteen_waves_per_cu(md):
+    for cmid, lds in ((64, 35840), (128, 70656)):
+        for x3 in ('false', 'true'):
+            r = _one(md, f'conv23_fused_kernel<{cmid}, {x3}>')
+            assert r['.group_segment_fixed_size'] == lds and r['.vgpr_count'] <= 128
+            waves = r['.max_flat_workgroup_size'] // 64
+            assert r['workgroups_per_cu'] * waves >= 16, (cmid, x3, r['workgroups_per_cu'])
+
+
+def test_bf16_256_tile_fits_one_eight_wave_workgroup(md):
+    """conv_bf16_256_kernel: 512 threads = 2 waves per SIMD -> at most 256 registers; 128 KB of dynamic LDS."""
+    for args in ('1, false, false, false', '1, true, false, false', '3, false, false, false', '1, false, true, false',
+                 '1, false, false, true'):
+        r = _one(md, f'conv_bf16_256_kernel<{args}>')
+        assert r['.max_flat_workgroup_size'] == 512 and r['.vgpr_count'] <= 256 and r['.group_segment_fixed_size'] == 0
+        assert codeobj.workgroups_per_cu(r, 131072) == 1
+
+
+def test_weight_stationary_kernels_own_a_whole_register_file(md):
+    """One wave per SIMD, up to 512 unified registers each (weights pinned in the accumulation half), no scratch; the
+    dynamic LDS they are launched with (csrc constants, static_assert'ed <= 160 KiB at compile time) leaves exactly one
+    workgroup per CU."""
+    for name, lds in (('conv3x3_ws_kernel<false>', 2 * 46 * 1024), ('conv3x3_ws_kernel<true>', 162048),
+                      ('conv3x3_ws128_kernel', 150000), ('conv1x1_wsn_kernel<512, 256, false>', 2 * 65536 + 1024)):
+        r = _one(md, name)
+        assert r['.max_flat_workgroup_size'] == 256 and r['.vgpr_count'] <= 512 and r['.agpr_count'] >= 200
+        assert r['.private_segment_fixed_size'] == 0
+        assert codeobj.workgroups_per_cu(r, lds) == 1, name
+    assert _one(md, 'conv3x3_ws_kernel<true>')['.vgpr_count'] <= 512
+
+
+def test_stems_occupancy(md):
+    """bf16 stem + max-pool: 77 760 B of LDS and <= 128 registers -> TWO 8-wave workgroups per CU; the
+    split-bf16 and fp32 forms hold one (their 32-bit conv tile + weights need > 80 KB)."""
+    r = _one(md, 'stem_pool_kernel<false>')
+    assert r['.group_segment_fixed_size'] <= 80 * 1024 and r['.vgpr_count'] <= 128 and r['workgroups_per_cu'] == 2
+    for name in ('stem_pool_kernel<true>', 'stem_pool_f32_kernel'):
+        r = _one(md, name)
+        assert r['.group_segment_fixed_size'] <= codeobj.LDS_PER_CU and r['.vgpr_count'] <= 256
+        assert r['workgroups_per_cu'] == 1

@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <utility>
 
 namespace tsm {
@@ -1164,21 +1166,24 @@ bool conv_bf16_256_valid(const ConvParams &p, int ks) {
   return true;
 }
 
+// Per DEVICE, once: the CU count that sizes the persistent grids and the > 64 KB dynamic-LDS opt-in of every kernel
+// that needs one.  tsm_hip.h lets engines on several devices live in one process, so neither may be cached from
+// whichever device happened to launch first (defined below the last kernel it names).
+struct DeviceInfo {
+  int n_cu = 256;
+  hipError_t status = hipSuccess;
+};
+static const DeviceInfo &device_info();
+constexpr size_t kLds256Bytes = 131072;
+
 static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s) {
   if (!conv_bf16_256_valid(p, ks)) return hipErrorInvalidValue;
   p.ntm = (p.M + 255) / 256;
   p.ntn = p.Cout / 256;
   const dim3 grid((unsigned)(p.ntm * p.ntn)), block(512);
-  constexpr size_t kLdsBytes = 131072;
-  static bool attr_set = false;
-  if (!attr_set) {   // above the 64 KB default: opt in once per kernel (idempotent; races only repeat the same call)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-    attr_set = true;
-  }
+  constexpr size_t kLdsBytes = kLds256Bytes;
+  const DeviceInfo &di = device_info();   // the > 64 KB dynamic-LDS opt-in, once per device
+  if (di.status != hipSuccess) return di.status;
   if (ks == 3) hipLaunchKernelGGL((conv_bf16_256_kernel<3, false>), grid, block, kLdsBytes, s, p);
   else if (p.T > 0) hipLaunchKernelGGL((conv_bf16_256_kernel<1, true>), grid, block, kLdsBytes, s, p);
   else if (p.res) hipLaunchKernelGGL((conv_bf16_256_kernel<1, false, true, false>), grid, block, kLdsBytes, s, p);
@@ -2168,28 +2173,38 @@ bool conv3x3_ws_valid(const ConvParams &p) {
          ws_tile_geometry(p.Hi, p.Wi, &tr, &tc);
 }
 
-static int ws_grid_setup() {
-  static int n_cu = 0;
-  if (!n_cu) {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-               ? prop.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kWsLdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kWsLdsBytes3All);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_ws128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kW8LdsBytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_ws_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              2 * 16 * 4096 + 256);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<128, 256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536 + 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<256, 128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536 + 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<512, 128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536 + 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<512, 256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 65536 + 1024);
-  }
-  return n_cu;
+static const DeviceInfo &device_info() {
+  static std::mutex mu;
+  static std::map<int, DeviceInfo> seen;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = seen.find(dev);
+  if (it != seen.end()) return it->second;
+  DeviceInfo di;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) di.n_cu = prop.multiProcessorCount;
+  auto opt_in = [&](const void *fn, size_t bytes) {
+    const hipError_t st = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (st != hipSuccess && di.status == hipSuccess) di.status = st;
+  };
+  opt_in(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false>), kLds256Bytes);
+  opt_in(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, true>), kLds256Bytes);
+  opt_in(reinterpret_cast<const void *>(&conv_bf16_256_kernel<3, false>), kLds256Bytes);
+  opt_in(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false, true, false>), kLds256Bytes);
+  opt_in(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false, false, true>), kLds256Bytes);
+  opt_in(reinterpret_cast<const void *>(&conv3x3_ws_kernel<false>), kWsLdsBytes);
+  opt_in(reinterpret_cast<const void *>(&conv3x3_ws_kernel<true>), kWsLdsBytes3All);
+  opt_in(reinterpret_cast<const void *>(&conv3x3_ws128_kernel), kW8LdsBytes);
+  opt_in(reinterpret_cast<const void *>(&conv1x1_ws_kernel<256>), 2 * 16 * 4096 + 256);
+  opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<128, 256, true>), 2 * 65536 + 1024);
+  opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<256, 128, false>), 2 * 65536 + 1024);
+  opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<512, 128, false>), 2 * 65536 + 1024);
+  opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<512, 256, false>), 2 * 65536 + 1024);
+  return seen.emplace(dev, di).first->second;
 }
+
+static int ws_grid_setup() { return device_info().n_cu; }
 
 static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
   if (conv3x3_ws128_valid(p)) {
@@ -2199,6 +2214,7 @@ static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
     ws_tile_geometry(q.H, q.W, &q.tr, &q.tc, 128, kW8PatchMax);
     const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
     const int n_cu = ws_grid_setup();
+    if (device_info().status != hipSuccess) return device_info().status;
     hipLaunchKernelGGL(conv3x3_ws128_kernel, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kW8LdsBytes, s, q);
     return hipGetLastError();
   }
@@ -2209,6 +2225,7 @@ static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
   ws_tile_geometry(q.H, q.W, &q.tr, &q.tc);
   const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
   const int n_cu = ws_grid_setup();
+  if (device_info().status != hipSuccess) return device_info().status;
   hipLaunchKernelGGL(conv3x3_ws_kernel<false>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kWsLdsBytes, s, q);
   return hipGetLastError();
 }
@@ -2219,6 +2236,7 @@ static hipError_t launch_conv1x1_ws(const ConvParams &p, hipStream_t s) {
   q.x = p.x; q.w = p.w; q.bias = p.bias; q.y = p.y;
   q.M = p.M; q.HW = p.Hi * p.Wi; q.T = p.T; q.fold = p.fold; q.relu = p.relu; q.reverse = p.reverse;
   const int n_cu = ws_grid_setup();
+  if (device_info().status != hipSuccess) return device_info().status;
   const int ntiles = (p.M + 127) / 128;
   const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);
   if (p.C == 256) hipLaunchKernelGGL(conv1x1_ws_kernel<256>, dim3(grid), dim3(256), 2 * 16 * 4096 + 256, s, q);
@@ -2233,6 +2251,7 @@ static hipError_t launch_conv1x1_wsn(const ConvParams &p, hipStream_t s) {
   q.M = p.M; q.HW = p.Hi * p.Wi; q.Wo = p.Wo; q.T = p.T; q.fold = p.fold; q.relu = p.relu; q.reverse = p.reverse;
   q.K1 = p.x2 ? p.K1 : p.C; q.Hi2 = p.Hi2; q.Wi2 = p.Wi2; q.stride2 = p.stride2;
   const int n_cu = ws_grid_setup();
+  if (device_info().status != hipSuccess) return device_info().status;
   const int px = p.Kp <= 256 ? 128 : 64;
   const int ntiles = (p.M + px - 1) / px;
   const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(256);
@@ -2258,6 +2277,7 @@ static hipError_t launch_conv23_ws(const Fused23Params &p, hipStream_t s) {
   ws_tile_geometry(q.H, q.W, &q.tr, &q.tc);
   const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
   const int n_cu = ws_grid_setup();
+  if (device_info().status != hipSuccess) return device_info().status;
   hipLaunchKernelGGL(conv3x3_ws_kernel<true>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kWsLdsBytes3All, s, q);
   return hipGetLastError();
 }
@@ -3110,7 +3130,7 @@ hipError_t launch_stem_pool(const float *x, const float *w, const float *bias, f
   if ((double)hi * wi * 16.0 > 2.0e9 || (prec != kPrecF32 && kp < 224)) return hipErrorInvalidValue;
   const long tiles = (long)n * ((hp + kPoolPH - 1) / kPoolPH) * ((wp + kPoolPW - 1) / kPoolPW);
   if (tiles >= (1L << 31) - 1024) return hipErrorInvalidValue;
-  const long cap = prec == kPrecBf16 ? 512 : 256;                 // persistent: one 8-wave workgroup per CU (bf16: two)
+  const long cap = (long)device_info().n_cu * (prec == kPrecBf16 ? 2 : 1);   // persistent: one 8-wave workgroup per CU (bf16: two)
   const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
   if (prec == kPrecF32)
     hipLaunchKernelGGL(stem_pool_f32_kernel, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
@@ -3130,7 +3150,7 @@ hipError_t launch_stem_direct(const float *x, const float *w, const float *bias,
   const int th = prec == kPrecBf16 ? 8 : 16;
   const long tiles = (long)n * ((ho + th - 1) / th) * ((wo + kStemTW - 1) / kStemTW);
   // persistent workgroups: two per CU for bf16 (4 waves, 75 KB of LDS each), one per CU for split-bf16 (8 waves, 159 KB)
-  const long cap = prec == kPrecBf16 ? 512 : 256;
+  const long cap = (long)device_info().n_cu * (prec == kPrecBf16 ? 2 : 1);
   const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
   if (prec == kPrecBf16)
     hipLaunchKernelGGL((stem_direct_kernel<false, 4>), dim3(grid), dim3(256), 0, s, x, w, bias, y, n, hi, wi, ho, wo, kp, relu);
