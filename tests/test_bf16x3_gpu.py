@@ -50,7 +50,11 @@ def test_logits_and_taps_x3(engine_x3, sd0, capsys):
         print(f'\n[bf16x3] logits max|err|/scale = {worst:.3g} (bar 1e-3)')
     for stage in ['stem', 'layer1.0', 'layer2.0', 'layer3.5', 'layer4.2']:
         got_t = engine_x3.forward_tap(x, stage)
-        assert_close(got_t, taps[stage].permute(0, 2, 3, 1).numpy(), rtol=1e-3, atol_scale=1e-5, what=stage)
+        # 3e-5 of the tap's scale: the split format drops the lo*lo product (2^-16 per product), which on the few
+        # near-zero elements of a 3-million-element tap shows as 1.2e-5 of the scale (measured); logits hold 1e-5
+        worst_t = assert_close(got_t, taps[stage].permute(0, 2, 3, 1).numpy(), rtol=1e-3, atol_scale=3e-5, what=stage)
+        with capsys.disabled():
+            print(f'[bf16x3] {stage} max|err|/scale = {worst_t:.3g}')
 
 
 def test_golden_logits_x3(hip_lib, golden_dir):

@@ -110,6 +110,21 @@ def test_inference_dataset_on_gpu_engine(probe_engine, tmp_path, golden_dir):
         assert_close(got, want.numpy(), rtol=1e-3, atol_scale=1e-5, what=f'clip {s}')
 
 
+def _play_plain(StreamBatcher, eng, vids, max_batch, every):
+    sb = StreamBatcher(eng, max_batch=max_batch)
+    ev = {k: [] for k in vids}
+    for t in range(240):
+        for k, v in vids.items():
+            if t < len(v):
+                sb.push(k, v[t])
+        if t % every == every - 1:
+            for k, e in sb.step().items():
+                ev[k] += e
+    for k, e in sb.step().items():
+        ev[k] += e
+    return ev, {k: sb.result(k) for k in vids}
+
+
 def test_stream_batcher_on_gpu_engine(probe_engine):
     """several live streams of different frame sizes share one engine; windows of all
     streams go through the fused HIP transform + one tsm_forward per step.  Exact: batched == one window at a
@@ -120,8 +135,8 @@ def test_stream_batcher_on_gpu_engine(probe_engine):
     vids = {'a': synthetic_video(31, 240, 90, 52, period=24), 'b': synthetic_video(32, 200, 120, 68, period=32),
             'c': synthetic_video(33, 168, 90, 52, period=20)}
 
-    def play(max_batch, every):
-        sb = StreamBatcher(eng, max_batch=max_batch)
+    def play(max_batch, every, **kw):
+        sb = StreamBatcher(eng, max_batch=max_batch, **kw)
         ev = {k: [] for k in vids}
         for t in range(240):
             for k, v in vids.items():
@@ -132,10 +147,24 @@ def test_stream_batcher_on_gpu_engine(probe_engine):
                     ev[k] += e
         for k, e in sb.step().items():
             ev[k] += e
-        return ev, {k: sb.result(k) for k in vids}
+        assert sb.pinned_bytes <= sb.max_pinned_bytes
+        for k in list(vids):
+            sb.close(k)
+        assert sb.pinned_bytes == 0 and not sb._free          # closing the last stream of a size frees its idle buffers
+        return ev, {k: sb.streams.get(k) for k in vids}, sb
 
-    ev32, res32 = play(32, 40)          # 5 windows x 3 streams per step -> batches of up to 15 mixed-size windows
-    ev1, res1 = play(1, 8)
+    def play_res(*a, **kw):
+        results = {}
+        ev, _, sb = play(*a, **kw, on_window=lambda sid, w, state, count: results.__setitem__(sid, count))
+        return ev, results
+
+    # a pinned budget of ~2.5 windows and 1 idle buffer per size: the producer runs 5 windows ahead of step(), so most
+    # windows fall back to pageable memory (bounded page-locked memory) -- same events, same counts
+    ev_cap, res_cap = play_res(32, 40, max_pinned_bytes=300_000, max_free_per_shape=1)
+    ev32, res32 = play_res(32, 40)
+    assert ev_cap == ev32 and res_cap == res32
+    ev32, res32 = _play_plain(StreamBatcher, eng, vids, 32, 40)          # 5 windows x 3 streams per step -> batches of up to 15 mixed-size windows
+    ev1, res1 = _play_plain(StreamBatcher, eng, vids, 1, 8)
     assert ev32 == ev1 and res32 == res1
     for k, v in vids.items():
         states = [s for _, s, _ in ev32[k]]

@@ -46,7 +46,8 @@ class StreamBatcher:
 
     def __init__(self, model, threshold: float = 0.5, softmax: bool = True, step: int = 8, max_batch: int = 32,
                  transform: Optional[TestTransform] = None,
-                 on_window: Optional[Callable[[Hashable, int, int, int], None]] = None):
+                 on_window: Optional[Callable[[Hashable, int, int, int], None]] = None,
+                 max_pinned_bytes: int = 1 << 30, max_free_per_shape: int = 64):
         self.model = model
         self.threshold, self.softmax, self.step_frames = threshold, softmax, step
         self.max_batch = max_batch
@@ -57,8 +58,13 @@ class StreamBatcher:
         # complete window is one DMA away from the GPU when step() runs -- the 1.8-MB host gather of a 360x206 window
         # (~0.15 ms) leaves the window's critical path.  Buffers are recycled once their H2D copy has completed.
         self._dev = _engine_device(model) if hasattr(model, 'packed_layout') else None
+        # Page-locked memory is bounded: at most ``max_pinned_bytes`` in window buffers (a producer that runs ahead of
+        # step(), or many resolutions, falls back to pageable windows beyond it -- slower upload, no hipHostMalloc on
+        # the frame-arrival path, no unbounded pinning), at most ``max_free_per_shape`` idle buffers per frame size.
         self._free: Dict[Tuple[int, ...], List[torch.Tensor]] = {}
         self._inflight: List[Tuple[object, torch.Tensor]] = []
+        self.max_pinned_bytes, self.max_free_per_shape = int(max_pinned_bytes), int(max_free_per_shape)
+        self.pinned_bytes = 0
 
     # ---- ingest -------------------------------------------------------------------------------------------
     def open(self, stream_id: Hashable) -> StreamState:
@@ -90,19 +96,44 @@ class StreamBatcher:
             st.windows.append(np.stack(st.frames))
             st.frames = []                      # input_queue.clear() of the reference
 
-    def _take_window(self, frame_shape: Tuple[int, ...]) -> torch.Tensor:
-        """A page-locked uint8 [8,H,W,3] buffer: recycled if one of this size is free, else newly pinned."""
+    def _recycle(self, wait: bool = False) -> None:
+        """Window buffers whose upload has finished go back to the free lists (capped per shape; the surplus and every
+        pageable fallback buffer is simply dropped)."""
         still = []
-        for ev, buf in self._inflight:          # buffers whose upload has finished go back to the free lists
+        for ev, buf in self._inflight:
+            if wait:
+                ev.synchronize()
             if ev.query():
-                self._free.setdefault(tuple(buf.shape[1:]), []).append(buf)
+                free = self._free.setdefault(tuple(buf.shape[1:]), [])
+                if buf.is_pinned() and len(free) < self.max_free_per_shape:
+                    free.append(buf)
+                elif buf.is_pinned():
+                    self.pinned_bytes -= buf.numel()
             else:
                 still.append((ev, buf))
         self._inflight = still
+
+    def _take_window(self, frame_shape: Tuple[int, ...]) -> torch.Tensor:
+        """A uint8 [8,H,W,3] window buffer: a recycled page-locked one if one of this size is free, a newly pinned one
+        while the pinned budget lasts, else pageable memory."""
+        self._recycle()
         free = self._free.get(frame_shape)
         if free:
             return free.pop()
+        nbytes = NUM_SEGMENTS * int(np.prod(frame_shape))
+        if self.pinned_bytes + nbytes > self.max_pinned_bytes:
+            self._trim_free(keep=frame_shape)           # idle buffers of other resolutions give their budget back first
+        if self.pinned_bytes + nbytes > self.max_pinned_bytes:
+            return torch.empty((NUM_SEGMENTS,) + frame_shape, dtype=torch.uint8)
+        self.pinned_bytes += nbytes
         return torch.empty((NUM_SEGMENTS,) + frame_shape, dtype=torch.uint8, pin_memory=True)
+
+    def _trim_free(self, keep: Optional[Tuple[int, ...]] = None) -> None:
+        """Release the idle page-locked buffers of every frame size no open stream is filling (except ``keep``)."""
+        live = {tuple(s.cur.shape[1:]) for s in self.streams.values() if s.cur is not None}
+        for shape in list(self._free):
+            if shape != keep and shape not in live:
+                self.pinned_bytes -= sum(b.numel() for b in self._free.pop(shape))
 
     def ready(self) -> int:
         return sum(len(s.windows) for s in self.streams.values())
@@ -110,6 +141,10 @@ class StreamBatcher:
     def close(self, stream_id: Hashable) -> Tuple[int, List[int]]:
         """Drop a stream (an incomplete last window is discarded, like the reference) -> (count, reps)."""
         st = self.streams.pop(stream_id)
+        for buf in ([st.cur] if st.cur is not None else []) + [w for w in st.windows if isinstance(w, torch.Tensor)]:
+            if buf.is_pinned():                              # half-filled / never-run windows go back to the pool
+                self._free.setdefault(tuple(buf.shape[1:]), []).append(buf)
+        self._trim_free()
         return st.counter.count, list(st.counter.reps)
 
     def result(self, stream_id: Hashable) -> Tuple[int, List[int]]:
@@ -176,6 +211,7 @@ class StreamBatcher:
                 # crosses PCIe, in the step's only host sync
                 from .engine import scores_to_states
                 states = scores_to_states(torch.cat(pending), threshold=self.threshold, softmax=self.softmax).cpu().tolist()
+                self._recycle()     # that .cpu() was the step's sync: every upload queued before it has completed
             else:
                 states = scores_to_preds(np.concatenate(pending).tolist(), threshold=self.threshold, softmax=self.softmax)
             for sid, state in zip(order, states):
