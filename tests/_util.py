@@ -26,6 +26,9 @@ def assert_close(got, want, rtol, atol_scale=1e-4, what=''):
 
 BF16_OP_RTOL = 2.0 ** -8      # half a bf16 ulp (8 significand bits) relative to the value: 3.9e-3
 BF16_E2E_BAR = 1e-2           # logits of the bf16 engine vs the bf16-storage oracle, fraction of the logit scale
+                              # (measured on MI355X: 3e-4 .. 2.9e-3 over the suite's shapes; vs the fp32 oracle 2e-3 .. 5e-3)
+BF16_TAP_BAR = 2e-2           # the same for the worst ELEMENT of a stage tap (millions of elements, up to 50 roundings
+                              # deep: measured 3e-3 after layer1.0 rising to 1.2e-2 after layer4.2)
 
 
 def assert_bf16_op(got, want_unrounded, what='', atol_scale=2e-5):

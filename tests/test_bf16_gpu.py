@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import tsm_oracle
-from tests._util import BF16_E2E_BAR, assert_bf16_op, assert_close, bf16_logits_report, make_input
+from tests._util import BF16_TAP_BAR, assert_bf16_op, assert_close, bf16_logits_report, make_input
 from tests.test_ops_gpu import CONV_CASES, _bn, _nchw, _nhwc
 
 pytestmark = pytest.mark.gpu
@@ -68,7 +68,7 @@ def test_bf16_engine_224_taps_and_packed_input(hip_lib, sd0, capsys):
     # Stage taps against the bf16-storage oracle.  The stem is one conv deep: every element must be the oracle's value
     # or its bf16 neighbour (a boundary flip).  Deeper taps: a flipped input moves each of its ~600 consumers by a tenth
     # of an ulp, so flips breed flips and the two roundings of the SAME network drift apart like a random walk in
-    # units of ulps -- the bar there is the distance in units of the tap's scale (logits bar), and it is reported.
+    # units of ulps -- the bar there is the worst element's distance in units of the tap's scale, and it is reported.
     t = taps['stem'].permute(0, 2, 3, 1).numpy()
     g = eng.forward_tap(x, 'stem')
     assert not (np.abs(g - t) > 2.0 ** -7 * np.abs(t) + 1e-5 * float(np.abs(t).max())).any(), 'stem'
@@ -77,7 +77,7 @@ def test_bf16_engine_224_taps_and_packed_input(hip_lib, sd0, capsys):
         e = float(np.abs(eng.forward_tap(x, stage) - t).max()) / float(np.abs(t).max())
         with capsys.disabled():
             print(f'[bf16 224] {stage}: max|err|/scale = {e:.3g} vs the bf16-storage oracle')
-        assert e <= BF16_E2E_BAR, stage
+        assert e <= BF16_TAP_BAR, stage
     vid = torch.from_numpy(synthetic_video(3, 16, 120, 90))
     packed = preprocess_frames(vid.cuda(), layout=eng.packed_layout, scale_255=True)
     assert eng.packed_layout == _lib.LAYOUT_NTHWC8B and tuple(packed.shape) == (16, 224, 112, 4)
