@@ -336,3 +336,35 @@ def test_weight_stationary_kernels_on_random_shapes_bitwise(hip_lib, monkeypatch
         outs[tile] = conv_bn_act_nhwc(_nhwc(x).cuda(), w.cuda(), *[b.cuda() for b in bn], stride=1, relu=True,
                                       shift_segments=shiftT, fold_div=8, dtype='bf16').cpu()
     assert torch.equal(outs['ws'], outs['64x64'])
+
+
+@pytest.mark.parametrize('h,w,b,t,div,shift', [
+    (256, 256, 2, 16, 8, True),    # the config-5 geometry: 64 x 64 frames at layer1, 33 steps per frame, T = 16
+    (224, 224, 2, 8, 8, True),     # the headline geometry: 56 x 56 (a step is 112 pixels: the fourth M-tile is half empty)
+    (90, 70, 3, 8, 8, True),       # 23 x 18: odd height (last step has one live row), M-tiles straddle the two rows
+    (64, 96, 4, 4, 8, True),       # 16 x 24 frames, T = 4: 16 frames over 16 workgroups
+    (72, 40, 3, 3, 8, True),       # 18 x 10 frames, odd segment count: more frames than some workgroups' share
+    (224, 224, 1, 8, 8, False),    # no temporal shift at all (FOLDG = 0)
+    (40, 250, 2, 8, 8, True),      # 10 x 63: the widest row the line buffer takes but one
+    (270, 480, 1, 8, 8, True),     # 68 x 120: too wide for the line buffer -- the forced switch must fall back, same bits
+])
+def test_whole_bottleneck_kernel_equals_the_separate_launches_bitwise(hip_lib, monkeypatch, h, w, b, t, div, shift):
+    """bneck_ws_kernel (layer1.1 / layer1.2 in bf16 as ONE launch: shift + conv1 into an LDS line buffer, conv2 from it,
+    conv3 + residual from an LDS mid tile; the block input streamed once) against the separate launches: block outputs
+    and logits bit for bit, on the BASELINE geometries, ragged sizes, with and without the shift."""
+    from workoutdetector_amd.engine import TsmEngine
+    from workoutdetector_amd.weights import make_state_dict
+    sd = make_state_dict(11, 12)
+    x = make_input(500 + h + t, b, t, h, w)
+    got = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('TSM_FUSE_BLOCK', flag)
+        eng = TsmEngine(num_segments=t, height=h, width=w, shift_div=div, is_shift=shift, max_clips=b, state_dict=sd, dtype='bf16')
+        got[flag] = [eng.forward_tap(x, s) for s in ('layer1.0', 'layer1.1', 'layer1.2', 'layer2.0')] + [eng.run(None, {'input': x})[0]]
+        tiles = eng.conv_tiles(b)
+        eng.close()
+        if flag == '0':
+            assert not any(v.endswith('+block') for v in tiles.values())
+    for name, a, c in zip(('layer1.0', 'layer1.1', 'layer1.2', 'layer2.0', 'logits'), got['1'], got['0']):
+        assert np.array_equal(a, c), name
+    assert np.isfinite(got['1'][-1]).all()

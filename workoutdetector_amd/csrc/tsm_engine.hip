@@ -111,6 +111,7 @@ struct tsm_engine {
   // HBM-bound formats, nothing in fp32).  TSM_ZIGZAG=0 switches it off.
   bool zigzag = true;
   int fuse23 = -1;   // TSM_FUSE_CONV23: 0 never, 1 wherever a block is eligible, unset: the autotuner times both forms
+  int fuse_block = -1;   // TSM_FUSE_BLOCK: the same for the whole-Bottleneck kernel (bf16, layer1.1 / layer1.2)
   int n_cu = 256;
   int timing_left = 0;
   bool timing_only3x3 = false;
@@ -338,7 +339,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   // against THIS layer: anything else falls back to the heuristic shape, so a stale, foreign or hand-edited cache
   // line can only cost speed.
   auto code_ok = [&](const tsm::ConvParams &p, int code) {
-    return code > 0 && (code & ~0x50F) == 0 && tsm::conv_tile_valid(p, code & 15);   // (0x400: block runs fused, below)
+    return code > 0 && (code & ~0xD0F) == 0 && tsm::conv_tile_valid(p, code & 15);   // (0x400 / 0x800: conv2 + conv3 / the whole block run fused, below)
   };
   int flip = 0;   // alternates the tile walk direction of consecutive conv launches (ConvParams::reverse)
   auto conv = [&](int idx, tsm::ConvParams p, int ks, bool is3x3) -> int {
@@ -447,6 +448,23 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       e->cur_timing->push_back(nullptr);
     }
     tsm::ConvParams p1 = make_params(c1, x, nullptr, t1, nn, hh, ww, true, shiftT, cfg.shift_div, prec);
+    // The WHOLE block as one launch (bf16, layer1.1 / layer1.2: bneck_ws_kernel): bit 0x800 of conv1's tile code (set by
+    // the tuning pass when it beat conv1 + the best conv2 / conv3 form), or forced / forbidden through TSM_FUSE_BLOCK
+    tsm::BneckParams pb{};
+    const bool can_block = prec == tsm::kPrecBf16 && blk.cmid == 64 && blk.down < 0 && c1.cin == 256 && e->fuse_block != 0 &&
+                           tsm::bneck_ws_valid(nn, hh, ww, shiftT, p1.fold) && !want(name + ".conv1") && !want(name + ".conv2");
+    if (can_block) {
+      pb.x = x; pb.w1 = c1.d_w; pb.bias1 = c1.d_b; pb.w2 = c2.d_w; pb.bias2 = c2.d_b; pb.w3 = c3.d_w; pb.bias3 = c3.d_b; pb.y = y;
+      pb.N = nn; pb.H = hh; pb.W = ww; pb.T = shiftT; pb.fold = p1.fold;
+    }
+    if (can_block && !tuning && (e->fuse_block == 1 || (tiles && ((*tiles)[blk.conv1] & 0x800)))) {
+      pb.reverse = e->zigzag ? (flip ^= 1) : 0;
+      TSM_LAUNCH_K(e, s, false, tsm::launch_bneck_ws(pb, s));
+      if (e->cur_timing)   // keep conv2's and conv3's launch slots: reported as "not recorded"
+        for (int k = 0; k < 4; ++k) e->cur_timing->push_back(nullptr);
+      if (want(name)) { tapped = true; return hit(y, nn, ho, wo, c3.cout); }
+      return TSM_OK;
+    }
     int rc1 = conv(blk.conv1, p1, 1, false);
     if (rc1) return rc1;
     if (want(name + ".conv1")) { tapped = true; return hit(t1, nn, hh, ww, c1.cout); }
@@ -482,11 +500,11 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     }
     int rc3 = conv(blk.conv3, p3, 1, false);
     if (rc3) return rc3;
-    if (tuning && can_fuse && e->fuse23 < 0) {
-      // Fused form against the two tuned separate launches (same bits), under ONE protocol: four repetitions, the
-      // first discarded, best of the other three, and the pair launched back to back inside one event bracket (so the
-      // inter-kernel boundary and conv3's cold start on conv2's output are priced, as they are in a real forward).
-      const int code2 = (*tiles)[blk.conv2], code3 = (*tiles)[blk.conv3];
+    if (tuning && ((can_fuse && e->fuse23 < 0) || (can_block && e->fuse_block < 0))) {
+      // Fused forms against the tuned separate launches (same bits), under ONE protocol: four repetitions, the first
+      // discarded, best of the other three, and a sequence of launches timed back to back inside one event bracket (so
+      // the inter-kernel boundaries and each kernel's cold start on its producer's output are priced, as in a forward).
+      const int code1 = (*tiles)[blk.conv1], code2 = (*tiles)[blk.conv2], code3 = (*tiles)[blk.conv3];
       auto best_of = [&](auto &&launch, float *out_ms) -> int {
         float ms[4];
         for (int rep = 0; rep < 4; ++rep) {
@@ -499,15 +517,32 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
         *out_ms = std::min(ms[1], std::min(ms[2], ms[3]));
         return TSM_OK;
       };
-      float pair_ms = 0.f, fused_ms = 0.f;
-      int rcp = best_of([&]() -> hipError_t {
+      auto pair = [&]() -> hipError_t {
         hipError_t st = launch_code(p2, 3, code2);
         return st != hipSuccess ? st : launch_code(p3, 1, code3);
-      }, &pair_ms);
-      if (rcp) return rcp;
-      rcp = best_of([&]() -> hipError_t { return tsm::launch_conv23_fused(pf, blk.cmid, prec, s); }, &fused_ms);
-      if (rcp) return rcp;
-      if (fused_ms < pair_ms) (*tiles)[blk.conv2] |= 0x400;
+      };
+      bool use_fused = can_fuse && e->fuse23 == 1;
+      if (can_fuse && e->fuse23 < 0) {       // conv2 + conv3 as one kernel against the pair
+        float pair_ms = 0.f, fused_ms = 0.f;
+        int rcp = best_of(pair, &pair_ms);
+        if (rcp) return rcp;
+        rcp = best_of([&]() -> hipError_t { return tsm::launch_conv23_fused(pf, blk.cmid, prec, s); }, &fused_ms);
+        if (rcp) return rcp;
+        use_fused = fused_ms < pair_ms;
+        if (use_fused) (*tiles)[blk.conv2] |= 0x400;
+      }
+      if (can_block && e->fuse_block < 0) {   // the whole block as one kernel against conv1 + the better form of the rest
+        float rest_ms = 0.f, block_ms = 0.f;
+        int rcp = best_of([&]() -> hipError_t {
+          hipError_t st = launch_code(p1, 1, code1);
+          if (st != hipSuccess) return st;
+          return use_fused ? tsm::launch_conv23_fused(pf, blk.cmid, prec, s) : pair();
+        }, &rest_ms);
+        if (rcp) return rcp;
+        rcp = best_of([&]() -> hipError_t { return tsm::launch_bneck_ws(pb, s); }, &block_ms);
+        if (rcp) return rcp;
+        if (block_ms < rest_ms) (*tiles)[blk.conv1] |= 0x800;
+      }
     }
     if (want(name)) { tapped = true; return hit(y, nn, ho, wo, c3.cout); }
     return TSM_OK;
@@ -596,6 +631,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (const char *ft = getenv("TSM_CONV_TILE")) e->force_tile = tsm::conv_tile_from_name(ft);
   if (const char *fc = getenv("TSM_CONV_CODE")) e->force_code = atoi(fc);
   if (const char *f23 = getenv("TSM_FUSE_CONV23")) e->fuse23 = atoi(f23) != 0;
+  if (const char *fb = getenv("TSM_FUSE_BLOCK")) e->fuse_block = atoi(fb) != 0;
   if (const char *zz = getenv("TSM_ZIGZAG")) e->zigzag = atoi(zz) != 0;
   if (const char *tc = getenv("TSM_TUNE_CACHE")) {
     hipDeviceProp_t prop;
@@ -604,7 +640,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
                   (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess ? std::string(prop.gcnArchName) : "?") +
                   " T" + std::to_string(cfg->num_segments) + " " + std::to_string(cfg->height) + "x" +
                   std::to_string(cfg->width) + " dtype" + std::to_string(cfg->dtype) + " shift" +
-                  std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0) + "/" + std::to_string(e->fuse23);
+                  std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0) + "/" + std::to_string(e->fuse23) + "/" + std::to_string(e->fuse_block);
   }
   build_topology(e);
   st = hipSetDevice(cfg->device_id);
