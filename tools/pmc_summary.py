@@ -22,7 +22,7 @@ def main(cc_path, kt_path):
     lo, hi = packs[-2], packs[-1]
     cols = None
     for d in ids:
-        if not (lo <= d < hi) or not ('conv' in names[d] or 'stem_' in names[d]):
+        if not (lo <= d < hi) or not ('conv' in names[d] or 'stem_' in names[d] or 'bneck' in names[d]):
             continue
         c = per[d]
         if cols is None:

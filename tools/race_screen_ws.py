@@ -4,7 +4,7 @@ run REPS times back to back and every result is compared bit for bit with the ig
 staged patch / ring slot too early passes most runs and fails some; this looks for the some.
   per-op cases: the 'ws' tile against the 64x64 tile through tsm_conv_bn_act;
   engine cases: TSM_FUSE_CONV23=1 (bf16: layer1.1 / layer1.2 run conv3x3_ws_kernel<true>) against TSM_FUSE_CONV23=0,
-  block outputs and logits, several forwards per engine."""
+  block outputs and logits, several forwards per engine; TSM_FUSE_BLOCK=1 (bneck_ws_kernel) against TSM_FUSE_BLOCK=0."""
 import os
 import sys
 
@@ -68,5 +68,22 @@ for b, t, s in [(4, 8, 224), (8, 16, 256), (3, 8, 96), (2, 8, 90)]:
     bad += fails
     print(f'engine  bf16 B={b} T={t} {s}x{s}: {fails}/{REPS} fused forwards differ from the separate launches')
 os.environ.pop('TSM_FUSE_CONV23', None)
+# bneck_ws_kernel (whole layer1.1 / layer1.2 block: wave-private LDS-DMA slots re-armed a step ahead, a four-row line buffer
+# and a mid tile re-used every step behind two barriers, counted vmcnt over [residual | input | stores]): TSM_FUSE_BLOCK=1
+# against the separate launches, many frames per workgroup (several engines' worth of steps), ragged and tiny frames
+for b, t, s in [(8, 16, 256), (48, 16, 256), (32, 8, 224), (3, 8, 96), (2, 8, 90), (40, 3, 64)]:
+    x = np.random.default_rng(7 * b + s).standard_normal((b, t, 3, s, s)).astype(np.float32)
+    outs = {}
+    for flag in ('0', '1'):
+        os.environ['TSM_FUSE_BLOCK'] = flag
+        eng = TsmEngine(num_segments=t, height=s, width=s, max_clips=b, state_dict=sd, dtype='bf16')
+        outs[flag] = []
+        for _ in range(1 if flag == '0' else max(4, REPS // 3)):
+            outs[flag].append((eng.forward_tap(x, 'layer1.1'), eng.forward_tap(x, 'layer1.2'), eng.run(None, {'input': x})[0]))
+        eng.close()
+    fails = sum(int(not all(np.array_equal(a, r) for a, r in zip(o, outs['0'][0]))) for o in outs['1'])
+    bad += fails
+    print(f'engine  bf16 B={b} T={t} {s}x{s}: {fails}/{len(outs["1"])} whole-block forwards differ from the separate launches')
+os.environ.pop('TSM_FUSE_BLOCK', None)
 print('RACE SCREEN', 'FAILED' if bad else 'clean')
 sys.exit(1 if bad else 0)
