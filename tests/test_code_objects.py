@@ -95,8 +95,9 @@ def test_whole_bottleneck_kernel_budget(md):
     """bneck_ws_kernel: 272 resident weight registers + the step's working set inside one wave's 512, NO scratch (a spill in
     its step loop would also break its counted vmcnt waits: scratch accesses count as vector-memory operations), and
     150 016 B of dynamic LDS = one workgroup per CU."""
-    for foldg in (0, 2):
-        r = _one(md, f'bneck_ws_kernel<{foldg}>')
-        assert r['.max_flat_workgroup_size'] == 256 and r['.vgpr_count'] <= 512 and r['.agpr_count'] >= 200
-        assert r['.private_segment_fixed_size'] == 0 and r['.vgpr_spill_count'] == 0
-        assert codeobj.workgroups_per_cu(r, 150016) == 1
+    for cin, lds in ((256, 150016), (64, 133632)):
+        for shift in ('true', 'false'):
+            r = _one(md, f'bneck_ws_kernel<{cin}, {shift}>')
+            assert r['.max_flat_workgroup_size'] == 256 and r['.vgpr_count'] <= 512 and r['.agpr_count'] >= 160
+            assert r['.private_segment_fixed_size'] == 0 and r['.vgpr_spill_count'] == 0
+            assert codeobj.workgroups_per_cu(r, lds) == 1

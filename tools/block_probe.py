@@ -42,7 +42,7 @@ for flag in ('0', '1', ''):
     tiles = eng.conv_tiles(B)
     print(f'TSM_FUSE_BLOCK={flag or "auto"}: {dt * 1e3:.3f} ms/forward  {B / dt:.1f} clips/s', flush=True)
     for k in names:
-        if k.startswith(('layer1.1', 'layer1.2')):
+        if k.startswith('layer1.'):
             print(f'   {k:22s} {avg[k] * 1e3:8.1f} us  {tiles.get(k, "")}')
     res[flag or 'auto'] = out.cpu()
     eng.close()

@@ -448,14 +448,18 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       e->cur_timing->push_back(nullptr);
     }
     tsm::ConvParams p1 = make_params(c1, x, nullptr, t1, nn, hh, ww, true, shiftT, cfg.shift_div, prec);
-    // The WHOLE block as one launch (bf16, layer1.1 / layer1.2: bneck_ws_kernel): bit 0x800 of conv1's tile code (set by
-    // the tuning pass when it beat conv1 + the best conv2 / conv3 form), or forced / forbidden through TSM_FUSE_BLOCK
+    // The WHOLE block as one launch (bf16 layer1: bneck_ws_kernel -- layer1.1 / layer1.2 with the block input as the
+    // residual, layer1.0 with the fused conv3 + downsample weights): bit 0x800 of conv1's tile code (set by the tuning
+    // pass when it beat conv1 + the best conv2 / conv3 form), or forced / forbidden through TSM_FUSE_BLOCK
     tsm::BneckParams pb{};
-    const bool can_block = prec == tsm::kPrecBf16 && blk.cmid == 64 && blk.down < 0 && c1.cin == 256 && e->fuse_block != 0 &&
-                           tsm::bneck_ws_valid(nn, hh, ww, shiftT, p1.fold) && !want(name + ".conv1") && !want(name + ".conv2");
+    const bool block_shape = prec == tsm::kPrecBf16 && blk.stride == 1 && c1.cout == 64 && c2.cin == 64 && c2.cout == 64 && c3.cout == 256 &&
+                             ((blk.down < 0 && c1.cin == 256) || (fused && c1.cin == 64 && e->convs[blk.down >= 0 ? blk.down : 0].cp == 64));
+    const bool can_block = block_shape && e->fuse_block != 0 && tsm::bneck_ws_valid(c1.cin, nn, hh, ww, shiftT, p1.fold) &&
+                           !want(name + ".conv1") && !want(name + ".conv2");
     if (can_block) {
-      pb.x = x; pb.w1 = c1.d_w; pb.bias1 = c1.d_b; pb.w2 = c2.d_w; pb.bias2 = c2.d_b; pb.w3 = c3.d_w; pb.bias3 = c3.d_b; pb.y = y;
-      pb.N = nn; pb.H = hh; pb.W = ww; pb.T = shiftT; pb.fold = p1.fold;
+      pb.x = x; pb.w1 = c1.d_w; pb.bias1 = c1.d_b; pb.w2 = c2.d_w; pb.bias2 = c2.d_b; pb.y = y;
+      pb.w3 = fused ? blk.d_wf : c3.d_w; pb.bias3 = fused ? blk.d_bf : c3.d_b;
+      pb.cin = c1.cin; pb.N = nn; pb.H = hh; pb.W = ww; pb.T = shiftT; pb.fold = p1.fold;
     }
     if (can_block && !tuning && (e->fuse_block == 1 || (tiles && ((*tiles)[blk.conv1] & 0x800)))) {
       pb.reverse = e->zigzag ? (flip ^= 1) : 0;

@@ -86,23 +86,26 @@ hipError_t launch_conv23_fused(const Fused23Params &p, int cmid, int prec, hipSt
 // Does the bf16 form apply to n frames of h x w pixels?
 bool conv23_ws_valid(int n, int h, int w);
 
-// A whole Bottleneck of layer1 without a downsample branch in ONE launch (bf16, bneck_ws_kernel): temporal shift -> conv1 (1x1,
-// 256 -> 64) -> conv2 (3x3) -> conv3 (1x1, 64 -> 256) + block input -> ReLU.  Neither 64-channel tensor exists in memory and the
-// block input is streamed once.  Bit-identical to the three separate launches.  Operands as launch_conv takes them (bf16 packed).
+// A whole Bottleneck of layer1 in ONE launch (bf16, bneck_ws_kernel): temporal shift -> conv1 (1x1, cin -> 64) -> conv2 (3x3) ->
+// conv3 (1x1, 64 -> 256) + identity -> ReLU.  cin = 256 (layer1.1 / layer1.2): the identity is the block input, w3 = conv3's
+// packed weights [256][64]; cin = 64 (layer1.0): the identity is the downsample branch, K-concatenated behind conv3 as in the
+// engine's fused conv3 + downsample GEMM: w3 = [256][64 mid | 64 input] and bias3 = conv3's + the downsample's.  Neither
+// 64-channel tensor exists in memory and the block input is streamed once.  Bit-identical to the separate launches.
 struct BneckParams {
-  const void *x;       // [N, H, W, 256] bf16: the block input (conv1's input through the shift, and the residual)
-  const void *w1;      // [64][256] bf16
+  const void *x;       // [N, H, W, cin] bf16: the block input (conv1's input through the shift, and the identity operand)
+  const void *w1;      // [64][cin] bf16
   const float *bias1;  // [64]
   const void *w2;      // [64][576] bf16, K = (ky, kx, c)
   const float *bias2;  // [64]
-  const void *w3;      // [256][64] bf16
+  const void *w3;      // [256][64] bf16, or [256][128] with the downsample weights behind conv3's (cin = 64)
   const float *bias3;  // [256]
   void *y;             // [N, H, W, 256] bf16
+  int cin;             // 256 or 64
   int N, H, W;
-  int T, fold;         // temporal shift over T segments (0 = none), fold = 256 / shift_div
+  int T, fold;         // temporal shift over T segments (0 = none), fold = cin / shift_div
   int reverse;         // walk the frames from the last one to the first
 };
-bool bneck_ws_valid(int n, int h, int w, int T, int fold);
+bool bneck_ws_valid(int cin, int n, int h, int w, int T, int fold);
 hipError_t launch_bneck_ws(const BneckParams &p, hipStream_t s);
 
 // Stem (7x7 s2 p3, 3 -> 64) of the bf16 formats as a direct convolution from an LDS-resident pixel-pair patch; x is the

@@ -2174,57 +2174,72 @@ bool conv3x3_ws_valid(const ConvParams &p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// bneck_ws: a WHOLE Bottleneck of layer1 without a downsample branch (layer1.1 / layer1.2 in bf16: temporal shift ->
-// conv1 1x1 256 -> 64 -> conv2 3x3 64 -> 64 -> conv3 1x1 64 -> 256 -> + block input -> ReLU) in ONE launch.
+// bneck_ws: a WHOLE Bottleneck of layer1 in bf16 as ONE launch -- temporal shift -> conv1 (1x1, CIN -> 64) -> conv2 (3x3,
+// 64 -> 64) -> conv3 (1x1, 64 -> 256) -> + identity -> ReLU.  Two forms:
+//   CIN = 256  layer1.1 / layer1.2: the identity is the block input itself (residual add in conv3's epilogue);
+//   CIN = 64   layer1.0: the identity is the downsample branch, a 1x1 conv of the block input -- as in the engine's fused
+//              conv3 + downsample GEMM it is K-concatenated behind conv3 (K = [64 mid | 64 input channels], one packed
+//              weight matrix [256][128], one bias), so the block input enters conv3 as a second B operand.
 //
 // Why: after conv3x3_ws_kernel<true> a layer1 block is two launches that each sit on the HBM roofline (conv1: 2.7 GB at
 // 5.2 TB/s; conv2 + conv3: 4.8 GB at 4.7 TB/s): the only lever left is bytes.  Here the 64-channel tensor between
-// conv1 and conv2 never exists in memory either, and the block input is streamed ONCE for conv1; its second use, the
-// residual, re-reads rows this CU fetched two steps earlier (L2 / Infinity-Cache resident) instead of a tensor last
-// touched a launch ago.  Algorithmic HBM bytes per frame: read H*W*512 + write H*W*512 (conv1 + fused: 3.5x that).
+// conv1 and conv2 never exists in memory either, and the block input is streamed ONCE for conv1; its second use (the
+// residual / the downsample operand) re-reads rows this CU fetched one or two steps earlier (L2 / Infinity-Cache
+// resident) instead of a tensor last touched a launch ago.  Algorithmic HBM bytes per frame: read H*W*CIN*2 + write
+// H*W*512 (the separate launches: 3.5x that for CIN = 256).
 //
 // Structure (one persistent workgroup of four waves per CU, one wave per SIMD, WHOLE FRAMES per workgroup):
 //   * a frame is walked top to bottom in steps of two rows.  Step s computes conv1 for rows 2s, 2s + 1 into a LINE
 //     BUFFER of four rows in LDS (row r lives in slot (r + 2) & 3; columns 0 and W + 1 and the rows above / below the
 //     frame are zeros = conv2's padding), then conv2 + conv3 for output rows 2s - 1, 2s, which need exactly the four
 //     buffered rows 2s - 2 .. 2s + 1.  conv1 is computed once per pixel: no halo recompute, no halo re-read.
-//   * weights live in registers, DISTRIBUTED over the waves: W1 whole (32 fragments; every wave multiplies its own 32
-//     pixels by all 64 mid channels), W2's 32-output-channel slice nt = wave & 1 (36 fragments), W3's 64-output-channel
-//     slice of the wave (8 fragments, parked in LDS between steps): 272 resident registers, most of them in the accumulation half of the file.
-//   * conv1: the step's 2W pixels are consecutive in memory (full-width rows), 32 per wave.  A wave's 32 pixels x 256
-//     channels arrive by LDS-DMA in a wave-private 16-KB slot (16 planes of 32-byte pixel halves, conv1x1_ws's layout;
-//     the temporal shift is the choice of source frame per plane, zeros at the clip's ends), fetched a whole step
-//     ahead: the slot is re-armed as soon as its fragments are in registers, so 64 KB of the next step's input are in
-//     flight per CU while this step computes.  No workgroup barrier inside the phase.
+//   * weights live in registers, DISTRIBUTED over the waves: W1 whole (every wave multiplies its own 32 pixels by all 64
+//     mid channels), W2's 32-output-channel slice nt = wave & 1 (36 fragments); W3's 64-output-channel slice of the
+//     wave is parked in LDS between steps (its registers are the conv2 phase's pixel fragments).
+//   * conv1: the step's 2W pixels are consecutive in memory (full-width rows), 32 per wave.  A wave's 32 pixels x CIN
+//     channels arrive by LDS-DMA in a wave-private slot (CIN / 16 planes of 32-byte pixel halves, conv1x1_ws's layout;
+//     the temporal shift is the choice of source frame per 16-byte chunk, zeros at the clip's ends), fetched a whole
+//     step ahead: 64 KB (16 KB) of the next step's input are in flight per CU while this step computes.  No workgroup
+//     barrier inside the phase.
 //   * conv2: wave (nt, h) multiplies M-tiles 2h, 2h + 1 of the step's (up to) 128 output pixels by its W2 slice -- one
 //     pixel-fragment read per MFMA straight from the line buffer, conv3x3_ws128's loop -- and writes its 32 mid
 //     channels to a 16-KB LDS tile in B-fragment order (the K of conv3 is split over the wave pair, so the mid tensor
 //     crosses LDS once; it never leaves the CU).
-//   * conv3: wave w multiplies all four M-tiles by its 64 output channels; the residual comes straight from global
-//     memory into registers as 16-byte groups (prefetched at the top of the step, un-swapped with v_permlane32_swap into
-//     the accumulator layout), bias + residual + ReLU + bf16 in conv3x3_ws_kernel<true>'s arithmetic, 16-byte stores.
+//   * conv3: wave w multiplies all four M-tiles by its 64 output channels; the identity operand comes straight from
+//     global memory into registers, prefetched at the top of the step: CIN = 256 -- 16-byte groups of the residual,
+//     un-swapped with v_permlane32_swap into the accumulator layout, bias + residual + ReLU + bf16 in
+//     conv3x3_ws_kernel<true>'s arithmetic; CIN = 64 -- the input pixel's four B fragments, multiplied by the second
+//     half of the packed weights behind the mid tensor, bias + ReLU + bf16 as conv1x1_wsn<.., DUAL>.  16-byte stores.
 //   * two barriers per step; every vector-memory wait is a counted vmcnt over a fixed issue order per step
-//     [16 residual loads | 16 LDS-DMA of the next step's input | 16 stores].
+//     [16 identity loads | the LDS-DMA of the next step's input | 16 stores].
 // Products enter every accumulator in the separate kernels' order (conv1: k16 groups ascending; conv2: taps, then k16
-// groups; conv3: k16 groups) and the three epilogues are theirs: bit-identical to conv1x1_ws -> conv3x3_ws<true>.
-// Needs W <= 64 (a row of the line buffer), C = 256, CMID = 64, fold % 16 == 0.
+// groups; conv3: k16 groups, mid before input) and the three epilogues are theirs: bit-identical to the launches it replaces.
+// Needs W <= 64 (a row of the line buffer), CMID = 64, fold = CIN / 8.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBnRP = 66;                          // line-buffer row pitch in pixels: W + 2 <= 66
 constexpr int kBnT1Plane = 4 * kBnRP * 32;         // one k16 group of the four buffered rows
 constexpr int kBnT1Bytes = 4 * kBnT1Plane;         // 33 792 B
 constexpr int kBnMidPlane = 128 * 32;
 constexpr int kBnMidOff = kBnT1Bytes;
-constexpr int kBnXOff = kBnMidOff + 4 * kBnMidPlane;            // four wave-private input slots of 16 KB
-constexpr int kBnW3Off = kBnXOff + 4 * 16384;                   // conv3's weights in fragment order: [it * 4 + g][lane] 16 B
-constexpr int kBnBiasOff = kBnW3Off + 32768;
-constexpr int kBnLdsBytes = kBnBiasOff + (64 + 64 + 256) * 4;   // 150 016 B
+constexpr int kBnXOff = kBnMidOff + 4 * kBnMidPlane;            // four wave-private input slots
+template <int CIN> struct BnLds {
+  static constexpr int kSlot = 32 * CIN * 2;                    // 32 pixels x CIN channels: 16 KB / 4 KB
+  static constexpr int kW3Off = kBnXOff + 4 * kSlot;            // conv3's weights in fragment order: [it * NG3 + g][lane] 16 B
+  static constexpr int kNG3 = CIN == 64 ? 8 : 4;                // k16 groups of conv3's K (the downsample form: mid + input)
+  static constexpr int kBiasOff = kW3Off + 8 * kNG3 * 1024;
+  static constexpr int kBytes = kBiasOff + (64 + 64 + 256) * 4; // 150 016 B (CIN 256) / 133 632 B (CIN 64)
+};
 
-
-// FOLDG: k16 groups (of conv1's 16) that the temporal shift takes from frame t + 1, and as many from t - 1: fold / 16
-// (2 for shift_div 8, the only one the bf16 formats take; 0 without a shift) -- compile-time, so that a group's source row is a register
-// choice and not a table lookup.
-template <int FOLDG>
+// SHIFT: the temporal shift of conv1's input, fold = CIN / 8 channels from frame t + 1 and as many from t - 1 (the bf16
+// formats take shift_div 8 only) -- compile-time, so that a chunk's source row is a register choice and not a table lookup.
+template <int CIN, bool SHIFT>
 __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
+  constexpr bool DUAL = CIN == 64;
+  constexpr int NG1 = CIN / 16;                    // k16 groups of conv1 = planes of an input slot
+  constexpr int NG3 = BnLds<CIN>::kNG3;
+  constexpr int XROW = CIN * 2;                    // bytes per input pixel
+  constexpr int kSlot = BnLds<CIN>::kSlot, kW3Off = BnLds<CIN>::kW3Off, kBiasOff = BnLds<CIN>::kBiasOff;
+  constexpr int NDMA = NG1;                        // LDS-DMA operations per step
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   typedef __attribute__((address_space(3))) void lds_void;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2232,35 +2247,35 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
   const int half = lane >> 5, l31 = lane & 31;
   const int nt2 = wave & 1, hh = wave >> 1;
   const int H = p.H, W = p.W, W2 = 2 * W;
-  const int frame_bytes = H * W * 512;
+  const int xframe = H * W * XROW, yframe = H * W * 512;
   const int nsteps = H / 2 + 1;
 
   // ---- the stationary operands
-  const __amdgpu_buffer_rsrc_t rsrcW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w1), 0, 64 * 256 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w1), 0, 64 * CIN * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w2), 0, 64 * 576 * 2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w3), 0, 256 * 64 * 2, 0x00020000);
-  u32x4 w1r[2][16], w2r[36];
+  const __amdgpu_buffer_rsrc_t rsrcW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w3), 0, 256 * 16 * NG3 * 2, 0x00020000);
+  u32x4 w1r[2][NG1], w2r[36];
 #pragma unroll
   for (int s = 0; s < 36; ++s)
     w2r[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW2, ((nt2 * 32 + l31) * 576 + s * 16 + half * 8) * 2, 0, 0);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int g = 0; g < 16; ++g)
-      w1r[nt][g] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW1, ((nt * 32 + l31) * 256 + g * 16 + half * 8) * 2, 0, 0);
-  // W3 (8 fragments per wave) stays in LDS: a step reads it once, into registers that are free in the conv3 phase
+    for (int g = 0; g < NG1; ++g)
+      w1r[nt][g] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW1, ((nt * 32 + l31) * CIN + g * 16 + half * 8) * 2, 0, 0);
+  // W3 (2 x NG3 fragments per wave) stays in LDS: a step reads it once, into registers that are free in the conv3 phase
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int fr = wave * 8 + k, it = fr >> 2, g = fr & 3;
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcW3, ((32 * it + l31) * 64 + 16 * g + 8 * half) * 2, 0, 0);
-    *reinterpret_cast<u32x4 *>(lds + kBnW3Off + fr * 1024 + lane * 16) = v;
+  for (int k = 0; k < 2 * NG3; ++k) {
+    const int fr = wave * 2 * NG3 + k, it = fr / NG3, g = fr - it * NG3;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrcW3, ((32 * it + l31) * (16 * NG3) + 16 * g + 8 * half) * 2, 0, 0);
+    *reinterpret_cast<u32x4 *>(lds + kW3Off + fr * 1024 + lane * 16) = v;
   }
 #pragma unroll
   for (int s = 0; s < 36; ++s) asm volatile("" : "+a"(w2r[s]));
 #pragma unroll
-  for (int g = 0; g < 16; ++g) asm volatile("" : "+a"(w1r[0][g]));
+  for (int g = 0; g < NG1; ++g) asm volatile("" : "+a"(w1r[0][g]));
 
-  float *bias1_lds = reinterpret_cast<float *>(lds + kBnBiasOff);
+  float *bias1_lds = reinterpret_cast<float *>(lds + kBiasOff);
   float *bias2_lds = bias1_lds + 64, *bias3_lds = bias1_lds + 128;
   if (tid < 64) {
     bias1_lds[tid] = p.bias1[tid];
@@ -2270,7 +2285,7 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
   for (int i = tid; i < kBnT1Bytes / 16; i += 256) *reinterpret_cast<u32x4 *>(lds + i * 16) = u32x4{0u, 0u, 0u, 0u};
 
   // ---- lane constants
-  unsigned char *xs = lds + kBnXOff + wave * 16384;                     // this wave's input slot
+  unsigned char *xs = lds + kBnXOff + wave * kSlot;                     // this wave's input slot
   const unsigned xrd = (unsigned)(l31 * 32 + ((half ^ ((l31 >> 3) & 1)) << 4));   // fragment read: pixel l31 of the slot
   const int pd = lane >> 1;                                             // loader: pixel of the slot, half (lane & 1)
   const int hsel = (lane & 1) ^ ((lane >> 4) & 1);
@@ -2280,23 +2295,26 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
   const int dr1 = m1 >= W ? 1 : 0, c1 = m1 - dr1 * W;
   const bool ok1 = m1 < W2;
 
-  // LDS-DMA of the input of step s of frame f into this wave's slot: always 16 operations (dead ones fetch nothing)
+  // LDS-DMA of the input of step s of frame f into this wave's slot: always NDMA operations (dead ones fetch nothing)
   auto issue_x = [&](int f, int s, bool live) {
     const int tt = p.T > 0 ? f % p.T : 0;
     // the descriptor starts one frame BEFORE f (only ever addressed there when frame t - 1 exists)
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.x) + ((long)f - 1) * frame_bytes), 0, 3 * frame_bytes, 0x00020000);
+        const_cast<char *>(reinterpret_cast<const char *>(p.x) + ((long)f - 1) * xframe), 0, 3 * xframe, 0x00020000);
     const int pix = 2 * s * W + md;
     const bool okp = live && md < W2 && pix < H * W;
-    // three source rows per pixel: its own frame, frame t + 1 (k16 groups < foldg), frame t - 1 (the next foldg groups);
-    // the group's 32 bytes are the instruction's immediate offset, so a step costs three address registers, not sixteen
-    const unsigned own = (unsigned)frame_bytes + (unsigned)pix * 512u + (unsigned)hsel * 16u;
+    // three source rows per pixel: its own frame, frame t + 1, frame t - 1; a k16 group's 32 bytes are the instruction's
+    // immediate offset, so a step costs three address registers, not one per group
+    const unsigned own = (unsigned)xframe + (unsigned)pix * (unsigned)XROW + (unsigned)hsel * 16u;
     const unsigned vC = okp ? own : kInvalid;
-    const unsigned vA = (okp && tt < p.T - 1) ? own + (unsigned)frame_bytes : kInvalid;
-    const unsigned vB = (okp && tt > 0) ? own - (unsigned)frame_bytes : kInvalid;
-    static_for<16>([&](auto gc) __attribute__((always_inline)) {
+    const unsigned vA = (okp && tt < p.T - 1) ? own + (unsigned)xframe : kInvalid;
+    const unsigned vB = (okp && tt > 0) ? own - (unsigned)xframe : kInvalid;
+    // fold = CIN / 8 channels: CIN 256 -- k16 groups 0, 1 from t + 1 and 2, 3 from t - 1; CIN 64 -- ONE 16-byte chunk each:
+    // the two halves of k16 group 0 (the loader lane's hsel picks the chunk)
+    const unsigned v0 = !SHIFT ? vC : (DUAL ? (hsel ? vB : vA) : vA);
+    static_for<NG1>([&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
-      const unsigned v = g < FOLDG ? vA : (g < 2 * FOLDG ? vB : vC);
+      const unsigned v = !SHIFT ? vC : (DUAL ? (g == 0 ? v0 : vC) : (g < 2 ? vA : (g < 4 ? vB : vC)));
       // (the instruction's immediate offset is added to the LDS address as well as to the memory address: the LDS base
       //  carries g * 1024 - g * 32 so that plane g still starts at g * 1024)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(xs + g * (1024 - 32)), 16, (int)v, 0, g * 32, 0);
@@ -2312,9 +2330,9 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
     const int f = p.reverse ? p.N - 1 - fi : fi;
     const int fnext = fi + (int)gridDim.x < p.N ? (p.reverse ? p.N - 1 - (fi + (int)gridDim.x) : fi + (int)gridDim.x) : -1;
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)f * frame_bytes), 0, frame_bytes, 0x00020000);
+        const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)f * xframe), 0, xframe, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char *>(p.y) + (size_t)f * frame_bytes, 0, frame_bytes, 0x00020000);
+        reinterpret_cast<char *>(p.y) + (size_t)f * yframe, 0, yframe, 0x00020000);
     // rows -2 and -1 of the new frame (slots 0, 1) are zeros; every wave is past the last conv2 of the previous frame
     for (int i = tid; i < 2 * kBnRP * 2 * 4; i += 256) {                // 2 slots x RP pixels x 2 halves, 4 planes
       const int pl = i / (2 * kBnRP * 2), r = i - pl * (2 * kBnRP * 2);
@@ -2324,17 +2342,26 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
       const int r0 = 2 * s - 1;                                         // output rows r0, r0 + 1; conv1 rows 2s, 2s + 1
       // ================= conv1: rows 2s, 2s + 1 -> line buffer =================
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                 // this step's input has landed (the 16 youngest operations are the previous step's stores)
-      // residual of this step's four M-tiles: res[mt][2 itl + qq] = bytes [64 it + 16 (2 half + qq), + 16) of the pixel.
-      // Issue order of a step's vector-memory operations: [8 residual loads, M-tiles 0-1 | 16 LDS-DMA of the next
-      // step's input | 8 residual loads, M-tiles 2-3 (at the top of the conv2 phase) | 16 stores] -- every wait below counts on it.
+      // The identity operand of this step's four M-tiles, 4 x 16 bytes per lane and M-tile:
+      //   CIN 256  res[mt][2 itl + qq] = bytes [64 it + 16 (2 half + qq), + 16) of the pixel's 512 (the store layout);
+      //   CIN 64   res[mt][g] = channels 16 g + 8 half .. + 8 of the pixel: the B fragment of k16 group g.
+      // Issue order of a step's vector-memory operations: [8 identity loads, M-tiles 0-1 (conv1 phase) | NDMA LDS-DMA of
+      // the next step's input | 8 identity loads, M-tiles 2-3 (top of the conv2 phase) | 16 stores] -- every wait below counts on it.
       u32x4 res[4][4];
       auto issue_res = [&](int mt) {
         const int m = 32 * mt + l31;
         const int dr = m >= W ? 1 : 0, c = m - dr * W, r = r0 + dr;
-        const unsigned o = (m < W2 && (unsigned)r < (unsigned)H) ? (unsigned)((r * W + c) * 512 + (2 * wave) * 64 + 2 * half * 16) : kInvalid;
+        const bool ok = m < W2 && (unsigned)r < (unsigned)H;
+        if constexpr (DUAL) {
+          const unsigned o = ok ? (unsigned)((r * W + c) * XROW + half * 16) : kInvalid;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)      // (the constant part rides in the scalar offset: one address register per M-tile)
-          res[mt][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)o, (k >> 1) * 64 + (k & 1) * 16, 0);
+          for (int g = 0; g < 4; ++g) res[mt][g] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)o, g * 32, 0);
+        } else {
+          const unsigned o = ok ? (unsigned)((r * W + c) * 512 + (2 * wave) * 64 + 2 * half * 16) : kInvalid;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)      // (the constant part rides in the scalar offset: one address register per M-tile)
+            res[mt][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)o, (k >> 1) * 64 + (k & 1) * 16, 0);
+        }
       };
       {
         f32x16 acc[2];
@@ -2342,13 +2369,14 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
-        u32x4 xf[8];
+        constexpr int GH = NG1 > 8 ? 8 : NG1;                           // the slot's fragments in batches of (at most) eight k16 groups
+        u32x4 xf[GH];
 #pragma unroll
-        for (int gh = 0; gh < 2; ++gh) {                                // the slot's fragments in two halves of eight k16 groups
+        for (int gh = 0; gh < NG1 / GH; ++gh) {
 #pragma unroll
-          for (int g = 0; g < 8; ++g) xf[g] = *reinterpret_cast<const u32x4 *>(xs + xrd + (8 * gh + g) * 1024);
+          for (int g = 0; g < GH; ++g) xf[g] = *reinterpret_cast<const u32x4 *>(xs + xrd + (GH * gh + g) * 1024);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (gh == 1) {
+          if (gh == NG1 / GH - 1) {
             issue_res(0);
             issue_res(1);
             // the slot is free (its fragments are in registers): fetch the next step's input, a whole step ahead
@@ -2356,10 +2384,10 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
             else issue_x(fnext < 0 ? f : fnext, 0, fnext >= 0);
           }
 #pragma unroll
-          for (int g = 0; g < 8; ++g)
+          for (int g = 0; g < GH; ++g)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1r[nt][8 * gh + g]), __builtin_bit_cast(bf16x8, xf[g]), acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1r[nt][GH * gh + g]), __builtin_bit_cast(bf16x8, xf[g]), acc[nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
         // bias1, ReLU, bf16; the swap pairs groups (0, 1) and (2, 3): this lane then holds channels 16 g' + 8 half .. + 8 of
@@ -2450,13 +2478,13 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();    // the mid tile is complete; the line buffer may be overwritten by the next step
-      // ================= conv3 + residual: all four M-tiles, output channels 64 wave .. + 64 =================
-      u32x4 w3r[2][4];
+      // ================= conv3 + identity: all four M-tiles, output channels 64 wave .. + 64 =================
+      u32x4 w3r[2][NG3];
 #pragma unroll
       for (int itl = 0; itl < 2; ++itl)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          w3r[itl][g] = *reinterpret_cast<const u32x4 *>(lds + kBnW3Off + ((2 * wave + itl) * 4 + g) * 1024 + lane * 16);
+        for (int g = 0; g < NG3; ++g)
+          w3r[itl][g] = *reinterpret_cast<const u32x4 *>(lds + kW3Off + ((2 * wave + itl) * NG3 + g) * 1024 + lane * 16);
       static_for<4>([&](auto mc) __attribute__((always_inline)) {
         constexpr int mt = decltype(mc)::value;
         const int ml = 32 * mt + l31;
@@ -2476,32 +2504,49 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
             c3[itl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w3r[itl][g]), __builtin_bit_cast(bf16x8, bf[g]), c3[itl], 0, 0, 0);
         const int dr = ml >= W ? 1 : 0, c = ml - dr * W, r = r0 + dr;
         const unsigned yo = (ml < W2 && (unsigned)r < (unsigned)H) ? (unsigned)((r * W + c) * 512 + (2 * wave) * 64 + 2 * half * 16) : kInvalid;
-        // this M-tile's residual; younger operations: M-tiles 0, 1 -- the other early residual loads, the next input (16), the
-        // late residual loads (8), the stores so far = 28; M-tiles 2, 3 -- the other late loads and the stores so far = 12
-        if constexpr (mt < 2) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        // this M-tile's identity operand; younger operations: M-tiles 0, 1 -- the other early loads (4 / 0), the next input
+        // (NDMA), the late loads (8), the stores so far (0 / 4) = NDMA + 12; M-tiles 2, 3 -- the other late loads and the
+        // stores so far = 12
+        if constexpr (mt < 2) wait_vmcnt(NDMA + 12);
+        else wait_vmcnt(12);
+        if constexpr (DUAL) {   // the downsample branch: K continues over the block input's 64 channels
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int itl = 0; itl < 2; ++itl)
+              c3[itl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w3r[itl][4 + g]), __builtin_bit_cast(bf16x8, res[mt][g]), c3[itl], 0, 0, 0);
+        }
 #pragma unroll
         for (int itl = 0; itl < 2; ++itl) {
-          // the residual's 16-byte groups -> accumulator layout: the store swap backwards
-          unsigned rp[4][2];
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
-              const auto sw = __builtin_amdgcn_permlane32_swap(res[mt][2 * itl + qq][w2], res[mt][2 * itl + qq][2 + w2], false, false);
-              rp[qq][w2] = sw[0];
-              rp[qq + 2][w2] = sw[1];
-            }
           unsigned pk[4][2];
+          if constexpr (DUAL) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(bias3_lds + (2 * wave + itl) * 32 + 8 * q + 4 * half);
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 b = *reinterpret_cast<const f32x4 *>(bias3_lds + (2 * wave + itl) * 32 + 8 * q + 4 * half);
+              pk[q][0] = pack_bf16(fmaxf(c3[itl][4 * q] + b[0], 0.f), fmaxf(c3[itl][4 * q + 1] + b[1], 0.f));
+              pk[q][1] = pack_bf16(fmaxf(c3[itl][4 * q + 2] + b[2], 0.f), fmaxf(c3[itl][4 * q + 3] + b[3], 0.f));
+            }
+          } else {
+            // the residual's 16-byte groups -> accumulator layout: the store swap backwards
+            unsigned rp[4][2];
 #pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
-              const unsigned rw = rp[q][w2];
-              f32x2 v = f32x2{c3[itl][4 * q + 2 * w2], c3[itl][4 * q + 2 * w2 + 1]} + f32x2{b[2 * w2], b[2 * w2 + 1]};
-              v += f32x2{__builtin_bit_cast(float, rw << 16), __builtin_bit_cast(float, rw & 0xFFFF0000u)};
-              pk[q][w2] = pack_bf16(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+              for (int w2 = 0; w2 < 2; ++w2) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(res[mt][2 * itl + qq][w2], res[mt][2 * itl + qq][2 + w2], false, false);
+                rp[qq][w2] = sw[0];
+                rp[qq + 2][w2] = sw[1];
+              }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const f32x4 b = *reinterpret_cast<const f32x4 *>(bias3_lds + (2 * wave + itl) * 32 + 8 * q + 4 * half);
+#pragma unroll
+              for (int w2 = 0; w2 < 2; ++w2) {
+                const unsigned rw = rp[q][w2];
+                f32x2 v = f32x2{c3[itl][4 * q + 2 * w2], c3[itl][4 * q + 2 * w2 + 1]} + f32x2{b[2 * w2], b[2 * w2 + 1]};
+                v += f32x2{__builtin_bit_cast(float, rw << 16), __builtin_bit_cast(float, rw & 0xFFFF0000u)};
+                pk[q][w2] = pack_bf16(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+              }
             }
           }
 #pragma unroll
@@ -2523,20 +2568,24 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
   }
 }
 
-bool bneck_ws_valid(int n, int h, int w, int T, int fold) {
-  return n > 0 && h > 0 && w >= 1 && w <= 64 && (double)h * w * 512.0 * 3.0 < 2.0e9 &&
-         (T == 0 || (T > 0 && n % T == 0 && fold == 32));
+bool bneck_ws_valid(int cin, int n, int h, int w, int T, int fold) {
+  return (cin == 256 || cin == 64) && n > 0 && h > 0 && w >= 1 && w <= 64 && (double)h * w * 512.0 * 3.0 < 2.0e9 &&
+         (T == 0 || (T > 0 && n % T == 0 && fold == cin / 8));
 }
 
 hipError_t launch_bneck_ws(const BneckParams &p, hipStream_t s) {
   if (!p.x || !p.w1 || !p.bias1 || !p.w2 || !p.bias2 || !p.w3 || !p.bias3 || !p.y) return hipErrorInvalidValue;
-  if (!bneck_ws_valid(p.N, p.H, p.W, p.T, p.fold)) return hipErrorInvalidValue;
+  if (!bneck_ws_valid(p.cin, p.N, p.H, p.W, p.T, p.fold)) return hipErrorInvalidValue;
   const DeviceInfo &di = device_info();
   if (di.status != hipSuccess) return di.status;
   const dim3 grid((unsigned)(p.N < di.n_cu ? p.N : di.n_cu)), block(256);
-  const int foldg = p.T > 0 ? p.fold / 16 : 0;
-  if (foldg == 2) hipLaunchKernelGGL(bneck_ws_kernel<2>, grid, block, kBnLdsBytes, s, p);
-  else hipLaunchKernelGGL(bneck_ws_kernel<0>, grid, block, kBnLdsBytes, s, p);
+  if (p.cin == 256) {
+    if (p.T > 0) hipLaunchKernelGGL((bneck_ws_kernel<256, true>), grid, block, BnLds<256>::kBytes, s, p);
+    else hipLaunchKernelGGL((bneck_ws_kernel<256, false>), grid, block, BnLds<256>::kBytes, s, p);
+  } else {
+    if (p.T > 0) hipLaunchKernelGGL((bneck_ws_kernel<64, true>), grid, block, BnLds<64>::kBytes, s, p);
+    else hipLaunchKernelGGL((bneck_ws_kernel<64, false>), grid, block, BnLds<64>::kBytes, s, p);
+  }
   return hipGetLastError();
 }
 
@@ -2563,8 +2612,10 @@ static const DeviceInfo &device_info() {
   opt_in(reinterpret_cast<const void *>(&conv3x3_ws_kernel<false>), kWsLdsBytes);
   opt_in(reinterpret_cast<const void *>(&conv3x3_ws_kernel<true>), kWsLdsBytes3All);
   opt_in(reinterpret_cast<const void *>(&conv3x3_ws128_kernel), kW8LdsBytes);
-  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<0>), kBnLdsBytes);
-  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<2>), kBnLdsBytes);
+  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, true>), BnLds<256>::kBytes);
+  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, false>), BnLds<256>::kBytes);
+  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<64, true>), BnLds<64>::kBytes);
+  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<64, false>), BnLds<64>::kBytes);
   opt_in(reinterpret_cast<const void *>(&conv1x1_ws_kernel<256>), 2 * 16 * 4096 + 256);
   opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<128, 256, true>), 2 * 65536 + 1024);
   opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<256, 128, false>), 2 * 65536 + 1024);
@@ -3449,8 +3500,12 @@ __global__ void __launch_bounds__(512) stem_pool_f32_kernel(const float *__restr
       const f32x4 a = *reinterpret_cast<const f32x4 *>(a_base + (ky * kPoolPCF + kx) * 16);
       const f32x4 b0 = *reinterpret_cast<const f32x4 *>(b_base + tap * 16);
       const f32x4 b1 = *reinterpret_cast<const f32x4 *>(b_base + 32 * WROW + tap * 16);
+      // Channels 0..2 only.  The generic kernel also multiplies the packed input's fourth channel -- +0 in the input
+      // (pack_input / tsm_preprocess write it) times +0 in the packed weights -- which leaves every accumulator bit as it
+      // is: an fp32 accumulator that starts at +0 is never -0 under round-to-nearest (x + (-x) and (+0) + (-0) are +0),
+      // so acc + (+0) == acc.  A quarter of the stem's MFMAs were those (K = 49 taps x 4 -> x 3: 200 -> 150 per tile).
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
+      for (int s4 = 0; s4 < 3; ++s4) {
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b0[s4], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b1[s4], acc[1], 0, 0, 0);
       }
