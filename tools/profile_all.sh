@@ -25,5 +25,7 @@ bash tools/pmc_sq.sh ${tag}_bf16c5 --config 5; cp $O/pmc_sq_${tag}_bf16c5.txt $O
 PMC="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
   bash tools/pmc_sq.sh ${tag}_bf16c5b --config 5; cp $O/pmc_sq_${tag}_bf16c5b.txt $O/${tag}_bf16c5_pmc_sq2.txt
 echo "== bf16x3 batch 32"; run_stats bf16x3 256 224 --dtype bf16x3
+DOMINANT="conv_igemm<128, 128, 4, 2, 3, false, false, 1, false, false>" UPDATE="32 8 224 224" bash tools/pmc_traffic.sh ${tag}_bf16x3 --dtype bf16x3 > $O/${tag}_bf16x3_hbm_traffic.txt 2>&1; tail -3 $O/${tag}_bf16x3_hbm_traffic.txt
+bash tools/pmc_sq.sh ${tag}_bf16x3 --dtype bf16x3; cp $O/pmc_sq_${tag}_bf16x3.txt $O/${tag}_bf16x3_pmc_sq.txt
 cp profiles/traffic.json $O/${tag}_traffic.json
 echo done
