@@ -20,8 +20,8 @@ What differs from the reference, on purpose:
     that is importable.
   * under ``torch.distributed`` a dataset run lays out the global (video, clip) index once: whole videos go to
     ranks longest-first by clip count, every rank runs full batches with no collective in its loop, and the
-    per-clip logits are all-gathered ONCE at the end (RCCL over xGMI with the nccl backend); rank 0 writes the
-    JSON (``shard='global'``).  ``shard='clips'`` splits the clips of each video instead (one all-gather per
+    per-clip logits are all-gathered ONCE at the end (RCCL over xGMI with the nccl backend); every rank writes
+    the JSON files of its own videos (``shard='global'``).  ``shard='clips'`` splits the clips of each video instead (one all-gather per
     video: the single-stream latency form); ``shard='videos'`` is the lock-stepped round-robin of round 2.
   * ``count_by_video_model`` in the reference snapshot is broken (asserts on the missing transform and
     always reads class 0 from an unsorted list, :270,:276,:327); this one implements the documented
@@ -254,7 +254,6 @@ def _staged_clips(model, st: StagedVideo, transform: TestTransform) -> Tuple[tor
     """Transformed frames of a staged clip range (each frame once), the [n_clips, 8] frame indices of its clips
     (the zero-padded tail points at one shared zero frame), and whether the frames are in the engine's packed
     device format (HIP transform) rather than float32 [n,3,224,224]."""
-    starts = clip_starts(st.total)
     dev = _engine_device(model)
     hip_transform = st.on_device and isinstance(transform, TestTransform)
     if hip_transform:
@@ -273,9 +272,14 @@ def _staged_clips(model, st: StagedVideo, transform: TestTransform) -> Tuple[tor
         frames = transform(even.permute(0, 3, 1, 2).to(torch.float32))        # [n_even, 3, 224, 224]
         zero = transform(torch.zeros((1, 3) + st.hw, dtype=torch.float32, device=frames.device))
         frames = torch.cat([frames, zero], dim=0)                              # + the zero-padded tail frame
+    # frame index of segment k of clip i: (start_i + 2k) / 2 - f_lo, or the shared zero frame past the end of the video.
+    # Built with tensor ops ON the frames' device: a host list -> device tensor copy would be a synchronous H2D that makes
+    # the host wait for everything queued on the stream (it was the per-video sync point of the dataset loop).
     zi = frames.shape[0] - 1
-    idx = torch.tensor([[(s // CLIP_STRIDE + k - st.f_lo) if (s + CLIP_STRIDE * k) < st.total else zi
-                         for k in range(NUM_SEGMENTS)] for s in starts[st.lo:st.hi]], device=frames.device)
+    dev_ = frames.device
+    first = CLIP_STEP * torch.arange(st.lo, st.hi, device=dev_, dtype=torch.int64)[:, None]
+    src = first + CLIP_STRIDE * torch.arange(NUM_SEGMENTS, device=dev_, dtype=torch.int64)[None, :]
+    idx = torch.where(src < st.total, src // CLIP_STRIDE - st.f_lo, torch.full_like(src, zi))
     return frames, idx, hip_transform
 
 
@@ -465,7 +469,7 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
     each to the least-loaded rank (``distributed.plan_video_shards``) -- every rank then decodes and runs ITS videos
     with full cross-video batches and NO collective inside the loop, and the job ends with one exchange: an
     all-gather of the per-video [index, frames, clips] table and ONE padded all-gather of the per-clip logits
-    ``[clips_on_rank, num_class]``; rank 0 writes the JSON files in dataset order."""
+    ``[clips_on_rank, num_class]`` (returned per video on every rank).  Each rank writes the JSON files of its own videos."""
     rank, world = tdist.world_info()
     dev = _engine_device(model)
     counts = [estimated_clips(it, frame_counter) for it in items]
@@ -490,12 +494,14 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
     num_class = getattr(model, 'num_class', None) or (int(per_video[0].shape[1]) if per_video else 0)
     local = (torch.cat([t.to(torch.float32).reshape(-1, num_class).cpu() for t in per_video], dim=0) if per_video
              else torch.empty((0, num_class), dtype=torch.float32))      # one D2H per rank, after its last forward
+    # every rank writes the files of ITS videos (a node's ranks share the file system): the serial JSON encoding of the
+    # whole dataset on rank 0 after the exchange would be the Amdahl term of the job (0.5 s of a 0.7-s share at W = 8)
+    pos = 0
+    for slot, v in enumerate(mine):
+        n = int(meta[slot, 2])
+        _write_score_json(out_dir, items[v], checkpoint, local[pos:pos + n], int(meta[slot, 1]))
+        pos += n
     if not tdist.collective_enabled():
-        pos = 0
-        for slot, v in enumerate(mine):
-            n = int(meta[slot, 2])
-            _write_score_json(out_dir, items[v], checkpoint, local[pos:pos + n], int(meta[slot, 1]))
-            pos += n
         return
     on_gpu = dev is not None and tdist.on_rccl()
     metas = tdist.all_gather_logits(meta.to(dev) if on_gpu else meta).cpu().reshape(world, len(items), 3)
@@ -505,18 +511,17 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
     pad = torch.zeros((per, ncls), dtype=torch.float32)
     pad[:local.shape[0]] = local.reshape(local.shape[0], ncls)
     every = tdist.all_gather_logits(pad.to(dev) if on_gpu else pad).cpu().reshape(world, per, ncls)
-    if rank == 0:
-        where = {}
-        for r in range(world):
-            pos = 0
-            for v, frames, n in metas[r].tolist():
-                if v >= 0:
-                    where[v] = (r, pos, n, frames)
-                    pos += n
-        assert sorted(where) == list(range(len(items))), 'every video must come back from exactly one rank'
-        for v, item in enumerate(items):
-            r, pos, n, frames = where[v]
-            _write_score_json(out_dir, item, checkpoint, every[r, pos:pos + n], frames)
+    # the exchange leaves every rank with the whole job's per-clip logits in dataset order (what the serial rep counter of
+    # utils/eval.py needs); the score files are already on disk
+    where = {}
+    for r in range(world):
+        pos = 0
+        for v, frames, n in metas[r].tolist():
+            if v >= 0:
+                where[v] = (r, pos, n, frames)
+                pos += n
+    assert sorted(where) == list(range(len(items))), 'every video must come back from exactly one rank'
+    return {items[v].video_name: every[where[v][0], where[v][1]:where[v][1] + where[v][2]] for v in range(len(items))}
 
 
 def inference_dataset(model, splits: List[str], out_dir: str, checkpoint: str, person_crop: bool = False,
@@ -540,8 +545,7 @@ def inference_dataset(model, splits: List[str], out_dir: str, checkpoint: str, p
         shard = 'global' if _world > 1 else 'clips'
     if shard not in ('clips', 'videos', 'global'):
         raise ValueError("shard must be 'clips', 'videos' or 'global'")
-    if rank == 0 and not os.path.exists(out_dir):
-        os.makedirs(out_dir)
+    os.makedirs(out_dir, exist_ok=True)       # (every rank: with shard='global' each writes the files of its own videos)
     data_root = osp.expanduser(data_root or '~/data/RepCount/')
     helper = RepcountHelper(data_root, anno_path or osp.join(data_root, 'annotation.csv'))
     data = helper.get_rep_data(splits, action=list(action))
