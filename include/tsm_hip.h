@@ -150,7 +150,9 @@ int tsm_layer_times(tsm_engine *e, int32_t forward_index, float *ms_out, int32_t
  * 5 = 128x128 on 8 waves, 6 = 256x256 LDS-DMA kernel (bf16), 7 = weight-stationary 3x3 (bf16, 64 -> 64 / 128 -> 128
  * channels), 0 = not tuned (heuristic); + 256 = split-K form of a segmented fp32 layer (one workgroup per tile and K
  * segment, combined in segment order); + 1024 (on conv2's code) = the block runs conv2 + conv3 + residual as ONE launch
- * (conv3's slot is then not used).  The first tsm_forward with a new power-of-two bucket of n_clips
+ * (conv3's slot is then not used); + 2048 (on conv1's code) = the WHOLE block -- shift, conv1, conv2, conv3 (+ the fused
+ * downsample branch) + identity -- runs as ONE launch (bf16 layer1; the conv2 / conv3 slots are then not used).
+ * The first tsm_forward with a new power-of-two bucket of n_clips
  * times every valid code per layer once (results are bit-identical across codes); TSM_AUTOTUNE=0 in the environment
  * at tsm_create disables it.  Every TSM_* environment variable is read once, in tsm_create. */
 int tsm_conv_tiles(tsm_engine *e, int32_t n_clips, int32_t *tiles_out, int32_t cap, int32_t *n_out);
