@@ -169,7 +169,9 @@ int tsm_temporal_shift(const float *x, float *y, int64_t n_frames, int32_t n_seg
  * shift_segments > 0 applies the temporal shift (fold_div) to x on the fly (k == 1, stride 1).
  * dtype: any tsm_dtype (x / residual / y stay fp32 NHWC at this boundary and are converted to and from
  * the storage format of that dtype around the kernel).
- * Packs the weights on every call: a test/debug entry point, not the fast path. */
+ * Packs the weights on every call: a test/debug entry point, not the fast path.  It has no engine, so it is the one
+ * place that reads tuning variables from the environment PER CALL: TSM_CONV_TILE (force a tile shape where valid) and
+ * TSM_STEM_DIRECT (bf16-format stems on the generic kernel); neither changes a result bit. */
 int tsm_conv_bn_act(const float *x, const float *w, const float *gamma, const float *beta,
                     const float *mean, const float *var, const float *residual, float *y,
                     int32_t n, int32_t hi, int32_t wi, int32_t cin, int32_t cout, int32_t k,
