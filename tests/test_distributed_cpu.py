@@ -183,6 +183,41 @@ def test_globally_sharded_inference_dataset_equals_single_process(tmp_path, gold
         assert open(os.path.join(single, f)).read() == open(os.path.join(alone, f)).read(), f
 
 
+def _dataset_global_anon_worker(rank, world, root, out_dir):
+    from tests._stub import StubModel
+    from workoutdetector_amd import inference_count as ic
+
+    class Anonymous(StubModel):          # a duck-typed session that does not say how many classes it has
+        num_class = None
+
+    got = ic.inference_dataset(Anonymous(), ['test'], out_dir, checkpoint='stub', data_root=root, batch_clips=4)
+    assert sorted(got) == sorted(f[:-len('.score.json')] for f in os.listdir(out_dir) if f.endswith('.json'))
+    assert all(tuple(v.shape)[1] == 12 for v in got.values())
+
+
+def test_global_sharding_with_a_rank_that_owns_no_video(tmp_path, golden_dir):
+    """Two videos over three ranks: rank 2 runs nothing and -- with a model that does not expose num_class -- cannot
+    know the class count; it must still take part in both exchanges (the count rides in the video table), every rank
+    gets the whole job's logits back, and the files equal the single-process run."""
+    import pandas as pd
+    from tests._stub import StubModel, synthetic_video
+    from workoutdetector_amd import inference_count as ic
+    from workoutdetector_amd.repcount import CLASSES
+    anno = pd.read_csv(f'{golden_dir}/repcount_annotation.csv', index_col=0)
+    rows = anno[(anno['split'] == 'test') & anno['class_'].isin(CLASSES)].head(2).copy()
+    rows['name'] = [n.replace('.mp4', '.npy') for n in rows['name']]
+    root = tmp_path / 'RepCount'
+    (root / 'videos' / 'test').mkdir(parents=True)
+    rows.to_csv(root / 'annotation.csv')
+    for i, name in enumerate(rows['name']):
+        np.save(root / 'videos' / 'test' / name, synthetic_video(i, (50, 19)[i], 40, 30))
+    single, sharded = str(tmp_path / 'single'), str(tmp_path / 'sharded')
+    ic.inference_dataset(StubModel(), ['test'], single, checkpoint='stub', data_root=str(root))
+    _spawn(_dataset_global_anon_worker, str(root), sharded, world=3)
+    for f in os.listdir(single):
+        assert open(os.path.join(single, f)).read() == open(os.path.join(sharded, f)).read(), f
+
+
 def test_global_shard_plan_is_balanced_on_the_repcount_val_distribution(golden_dir):
     """BASELINE config 4's own distribution (100 val videos, 2-327 clips, 10 062 in all, from the committed annotation):
     the longest-first plan keeps every rank within 5 % of the mean up to W = 8 with no exchange until the end, where

@@ -464,7 +464,7 @@ class _ClipBatcher:
 
 
 def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str, transform, reader, batch_clips: int,
-                              frame_counter: Optional[Callable[[str], int]] = None) -> None:
+                              frame_counter: Optional[Callable[[str], int]] = None) -> Dict[str, torch.Tensor]:
     """``shard='global'``: the (video, clip) index of the whole job is laid out once -- whole videos, longest first,
     each to the least-loaded rank (``distributed.plan_video_shards``) -- every rank then decodes and runs ITS videos
     with full cross-video batches and NO collective inside the loop, and the job ends with one exchange: an
@@ -476,12 +476,12 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
     owner = tdist.plan_video_shards(counts, world)
     mine = [v for v in range(len(items)) if owner[v] == rank]
     batcher = _ClipBatcher(model, batch_clips)
-    meta = torch.full((len(items), 3), -1, dtype=torch.int64)      # rows of MY videos: [video index, frames, clips]
+    meta = torch.full((len(items), 4), -1, dtype=torch.int64)      # rows of MY videos: [video index, frames, clips, classes]
     direct: Dict[int, torch.Tensor] = {}
     staged = prefetch_staged(model, ((v, (lambda p=items[v].video_path: reader(p))) for v in mine))
     for slot, (v, st) in enumerate(staged):
         n_clips = st.hi - st.lo
-        meta[slot] = torch.tensor([v, st.total, n_clips])
+        meta[slot, :3] = torch.tensor([v, st.total, n_clips])
         if n_clips == 0:
             batcher.rows.setdefault(v, [])
         elif (not st.on_device and dev is not None and hasattr(model, 'packed_layout')
@@ -502,12 +502,17 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
         _write_score_json(out_dir, items[v], checkpoint, local[pos:pos + n], int(meta[slot, 1]))
         pos += n
     if not tdist.collective_enabled():
-        return
+        out, pos = {}, 0
+        for slot, v in enumerate(mine):
+            n = int(meta[slot, 2])
+            out[items[v].video_name] = local[pos:pos + n]
+            pos += n
+        return out
     on_gpu = dev is not None and tdist.on_rccl()
-    metas = tdist.all_gather_logits(meta.to(dev) if on_gpu else meta).cpu().reshape(world, len(items), 3)
+    meta[:len(mine), 3] = num_class      # (a rank without videos does not know the class count: it rides in the table)
+    metas = tdist.all_gather_logits(meta.to(dev) if on_gpu else meta).cpu().reshape(world, len(items), 4)
     per = max(1, int(metas[:, :, 2].clamp(min=0).sum(dim=1).max()))
-    ncls = torch.tensor([[num_class]], dtype=torch.int64)
-    ncls = int(tdist.all_gather_logits(ncls.to(dev) if on_gpu else ncls).max()) if num_class == 0 else num_class
+    ncls = max(num_class, int(metas[:, :, 3].max()))
     pad = torch.zeros((per, ncls), dtype=torch.float32)
     pad[:local.shape[0]] = local.reshape(local.shape[0], ncls)
     every = tdist.all_gather_logits(pad.to(dev) if on_gpu else pad).cpu().reshape(world, per, ncls)
@@ -516,7 +521,7 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
     where = {}
     for r in range(world):
         pos = 0
-        for v, frames, n in metas[r].tolist():
+        for v, frames, n, _c in metas[r].tolist():
             if v >= 0:
                 where[v] = (r, pos, n, frames)
                 pos += n
@@ -528,7 +533,7 @@ def inference_dataset(model, splits: List[str], out_dir: str, checkpoint: str, p
                       data_root: Optional[str] = None, anno_path: Optional[str] = None,
                       video_reader: Optional[Callable[[str], torch.Tensor]] = None, action: Sequence[str] = ('all',),
                       batch_clips: int = 32, scale_255: bool = False, shard: Optional[str] = None,
-                      frame_counter: Optional[Callable[[str], int]] = None) -> None:
+                      frame_counter: Optional[Callable[[str], int]] = None) -> Optional[Dict[str, torch.Tensor]]:
     """Inference the RepCount dataset; one ``{video_name}.score.json`` per video with the reference's
     schema: video_name, model, input_shape, checkpoint, total_frames, ground_truth, action, scores.
 
@@ -556,10 +561,9 @@ def inference_dataset(model, splits: List[str], out_dir: str, checkpoint: str, p
     if shard == 'videos':
         _inference_dataset_by_videos(model, list(data.values()), out_dir, checkpoint, transform, reader, batch_clips)
         return
-    if shard == 'global':
-        _inference_dataset_global(model, list(data.values()), out_dir, checkpoint, transform, reader, batch_clips,
-                                  frame_counter)
-        return
+    if shard == 'global':     # (returns {video_name: logits [clips, classes]} on every rank; the reference returns None)
+        return _inference_dataset_global(model, list(data.values()), out_dir, checkpoint, transform, reader, batch_clips,
+                                         frame_counter)
     # Video i+1 is read, sliced, pinned and copied to the GPU by a worker thread while video i computes.
     videos = ((item, (lambda p=item.video_path: reader(p))) for item in data.values())
     for item, staged in prefetch_staged(model, videos, lambda v: _rank_clip_range(int(v.shape[0]))):
