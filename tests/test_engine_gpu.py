@@ -323,6 +323,40 @@ def test_tune_cache_file_round_trip(hip_lib, sd0, tmp_path, monkeypatch):
     assert len(path.read_text().splitlines()) == 2
 
 
+def test_tune_cache_keeps_the_fusion_bits(hip_lib, sd0, tmp_path, monkeypatch):
+    """A cached line whose codes carry the fusion bits (+1024: conv2 + conv3 as one launch, +2048: the whole block as one
+    launch) must be READ BACK, not rejected: the ranks of a multi-GPU job share one tune cache (rank 0 tunes, the others
+    read), and a parser that dropped such lines would make every rank tune for itself.  A bf16 engine at a batch where the
+    tuner picks the whole-block kernel writes its line; the line is then edited (every layer1 / layer2 fusion bit the
+    layer supports is set or cleared by hand) and a second engine must report exactly the edited codes."""
+    from workoutdetector_amd.engine import TsmEngine
+    path = tmp_path / 'tiles.txt'
+    monkeypatch.setenv('TSM_TUNE_CACHE', str(path))
+    x = make_input(52, 32, 8, 224, 224)[:32]
+    a = TsmEngine(max_clips=32, state_dict=sd0, dtype='bf16')
+    ya = a.run(None, {'input': x})[0]
+    tiles_a = a.conv_tiles(32)
+    a.close()
+    line = path.read_text().splitlines()[0]
+    key, codes = line.rsplit('|', 1)
+    codes = [int(c) for c in codes.split(',')]
+    assert any(c & 0x800 for c in codes) or any(c & 0x400 for c in codes), tiles_a     # the tuner uses a fused form at this size
+    names = [k for k in a.launch_names() if k not in ('pack_input', 'maxpool', 'head')]
+    flipped = list(codes)
+    for i, nme in enumerate(names):                      # toggle the whole-block bit of the three layer1 blocks
+        if nme in ('layer1.0.conv1', 'layer1.1.conv1', 'layer1.2.conv1'):
+            flipped[i] ^= 0x800
+    path.write_text(key + '|' + ','.join(str(c) for c in flipped) + '\n')
+    b = TsmEngine(max_clips=32, state_dict=sd0, dtype='bf16')
+    yb = b.run(None, {'input': x})[0]
+    tiles_b = b.conv_tiles(32)
+    b.close()
+    assert len(path.read_text().splitlines()) == 1, 'the edited line was rejected and the engine tuned again'
+    for nme in ('layer1.0.conv1', 'layer1.1.conv1', 'layer1.2.conv1'):
+        assert tiles_b[nme].endswith('+block') != tiles_a[nme].endswith('+block'), (nme, tiles_a[nme], tiles_b[nme])
+    assert np.array_equal(ya, yb)                         # and, as always, not a bit of the result depends on it
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16x3', 'bf16'])
 @pytest.mark.parametrize('h,w,b', [(224, 224, 2), (96, 96, 3), (90, 70, 1), (256, 256, 3)])
 def test_fused_conv2_conv3_equals_the_separate_kernels_bitwise(hip_lib, sd0, monkeypatch, h, w, b, dtype):
