@@ -341,9 +341,12 @@ def test_tune_cache_keeps_the_fusion_bits(hip_lib, sd0, tmp_path, monkeypatch):
     key, codes = line.rsplit('|', 1)
     codes = [int(c) for c in codes.split(',')]
     assert any(c & 0x800 for c in codes) or any(c & 0x400 for c in codes), tiles_a     # the tuner uses a fused form at this size
-    names = [k for k in a.launch_names() if k not in ('pack_input', 'maxpool', 'head')]
+    # the line is in the engine's layer order: stem, then per block conv1, conv2, conv3 (, downsample)
+    order = ['conv1'] + [f'layer{li}.{b}.{part}' for li, nb in enumerate((3, 4, 6, 3), 1) for b in range(nb)
+                         for part in ('conv1', 'conv2', 'conv3') + (('downsample',) if b == 0 else ())]
+    assert len(order) == len(codes) == 53
     flipped = list(codes)
-    for i, nme in enumerate(names):                      # toggle the whole-block bit of the three layer1 blocks
+    for i, nme in enumerate(order):                      # toggle the whole-block bit of the three layer1 blocks
         if nme in ('layer1.0.conv1', 'layer1.1.conv1', 'layer1.2.conv1'):
             flipped[i] ^= 0x800
     path.write_text(key + '|' + ','.join(str(c) for c in flipped) + '\n')
