@@ -202,3 +202,86 @@ def test_stream_batcher_matches_per_stream_counting():
     assert not sb.streams
     with pytest.raises(ValueError):
         sb.push('d', np.zeros((4, 4, 3), np.float32))
+
+
+def test_clip_batcher_hands_every_row_back_to_its_video():
+    """_ClipBatcher (full batches across video boundaries, the dataset loop of shard='global'): random video lengths --
+    empty ones, single clips, lengths below / equal to / far above the batch -- and random batch sizes; every video must
+    get exactly its own clips' rows, in order, and the model must see ceil(total / batch) calls (full batches)."""
+    rng = np.random.default_rng(7)
+
+    class Echo:                                # logits row = [video key, clip index, first pixel of the clip]
+        num_class = 3
+
+        def __init__(self):
+            self.calls = 0
+
+        def get_inputs(self):
+            from tests._stub import _Arg
+            return [_Arg('input')]
+
+        def run(self, _names, feed):
+            (x,) = feed.values()
+            self.calls += 1
+            return [np.stack([x[:, 0, 0, 0, 0], x[:, 0, 0, 0, 1], x[:, 0, 0, 0, 2]], axis=1).astype(np.float32)]
+
+    for _ in range(25):
+        batch = int(rng.integers(1, 9))
+        counts = [int(c) for c in rng.choice([0, 1, 2, 3, batch - 1, batch, batch + 1, 3 * batch + 2, 17], size=int(rng.integers(1, 7)))]
+        model = Echo()
+        batcher = ic._ClipBatcher(model, batch)
+        for key, n in enumerate(counts):
+            if n == 0:
+                batcher.rows.setdefault(key, [])
+                continue
+            # "frames": one distinguishable frame per clip; clip i gathers frame i eight times
+            frames = torch.zeros(n, 3, 2, 4)
+            frames[:, 0, 0, 0] = key
+            frames[:, 0, 0, 1] = torch.arange(n, dtype=torch.float32)
+            frames[:, 0, 0, 2] = torch.arange(n, dtype=torch.float32) * 0.5 + key
+            idx = torch.arange(n)[:, None].repeat(1, 8)
+            batcher.add(key, frames, idx, False)
+        batcher.flush()
+        for key, n in enumerate(counts):
+            rows = batcher.logits(key)
+            assert tuple(rows.shape)[0] == n
+            if n:
+                want = torch.stack([torch.full((n,), float(key)), torch.arange(n, dtype=torch.float32),
+                                    torch.arange(n, dtype=torch.float32) * 0.5 + key], dim=1)
+                assert torch.equal(rows.to(torch.float32), want), (counts, batch, key)
+        assert model.calls == -(-sum(counts) // batch), (counts, batch, model.calls)
+
+
+def test_estimated_clips_sources(tmp_path):
+    """The shard plan's clip estimate: a frame_counter callback, else the rawframes count, else a .npy header, else the
+    last annotated repetition frame -- never a decode."""
+    from workoutdetector_amd.repcount import RepcountItem
+    item = RepcountItem(str(tmp_path / 'v.npy'), str(tmp_path / 'raw'), -1, 'squat', 2, [3, 40, 41, 97], 'test', 'v.npy')
+    assert ic.estimated_clips(item) == len(range(0, 97, 8))                       # annotation only: 13 clips
+    np.save(tmp_path / 'v.npy', np.zeros((150, 4, 4, 3), dtype=np.uint8))
+    assert ic.estimated_clips(item) == len(range(0, 150, 8))                      # the .npy header: 19
+    item.total_frames = 64
+    assert ic.estimated_clips(item) == 8                                          # a rawframes directory wins
+    assert ic.estimated_clips(item, frame_counter=lambda p: 9) == 2               # a callback wins over everything
+    empty = RepcountItem('nowhere.mp4', '', -1, 'squat', 0, [], 'test', 'nowhere.mp4')
+    assert ic.estimated_clips(empty) == 1
+
+
+def test_bench_names_the_kernels_rocprof_prints():
+    """bench.kernel_of maps the tuner's tile names to kernel names; roofline.kernel / roofline.traffic are only right if
+    those are the names rocprofv3 prints.  Checked against the committed kernel-stats summaries of this round."""
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for mode in ('f32', 'bf16c5', 'bf16x3'):
+        text = open(os.path.join(root, 'profiles', f'r03_{mode}_kernel_stats.csv')).read()
+        seen[mode] = text
+    cases = [('f32', '64x64', 'f32', 256), ('f32', '64x64+conv3', 'f32', 128), ('f32', '64x64+conv3', 'f32', 64),
+             ('bf16c5', '256x256', 'bf16', 256), ('bf16c5', 'ws', 'bf16', 128), ('bf16x3', '128x128w8', 'bf16x3', 256),
+             ('bf16x3', '128x128+conv3', 'bf16x3', 128)]
+    for mode, tile, dtype, cmid in cases:
+        name, with_conv3 = bench.kernel_of(tile, dtype, cmid)
+        assert with_conv3 == tile.endswith('+conv3')
+        assert ('tsm::' + name) in seen[mode], (tile, dtype, cmid, name)
+    assert bench.kernel_of('ws+conv3', 'bf16', 64) == ('conv3x3_ws_kernel<true>', True)
+    assert bench.kernel_of('64x64/splitK', 'f32', 512)[0] == 'conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, true>'
