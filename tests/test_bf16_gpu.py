@@ -347,6 +347,8 @@ def test_weight_stationary_kernels_on_random_shapes_bitwise(hip_lib, monkeypatch
     (224, 224, 1, 8, 8, False),    # no temporal shift at all (FOLDG = 0)
     (40, 250, 2, 8, 8, True),      # 10 x 63: the widest row the line buffer takes but one
     (270, 480, 1, 8, 8, True),     # 68 x 120: too wide for the line buffer -- the forced switch must fall back, same bits
+    (32, 32, 5, 1, 8, True),       # the smallest engine: 8 x 8 frames, single-frame clips (both shifted groups read zeros)
+    (250, 256, 1, 4, 8, True),     # 63 x 64: the widest row with an odd height; 4 frames on 4 workgroups
 ])
 def test_whole_bottleneck_kernel_equals_the_separate_launches_bitwise(hip_lib, monkeypatch, h, w, b, t, div, shift):
     """bneck_ws_kernel (every layer1 block in bf16 as ONE launch: shift + conv1 into an LDS line buffer, conv2 from it,
