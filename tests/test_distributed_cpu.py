@@ -82,7 +82,7 @@ def test_sharded_inference_dataset_equals_single_process(tmp_path, golden_dir):
     for i, name in enumerate(rows['name']):
         np.save(root / 'videos' / 'test' / name, synthetic_video(i, frames[name], 40, 30))
     single, sharded = str(tmp_path / 'single'), str(tmp_path / 'sharded')
-    ic.inference_dataset(StubModel(), ['test'], single, checkpoint='stub', data_root=str(root))
+    ic.inference_dataset(StubModel(), ['test'], single, checkpoint='stub', data_root=str(root), shard='clips')
     _spawn(_dataset_worker, str(root), sharded)
     assert sorted(os.listdir(single)) == sorted(os.listdir(sharded))
     for f in os.listdir(single):
@@ -112,7 +112,7 @@ def test_video_sharded_inference_dataset_equals_single_process(tmp_path, golden_
     for i, name in enumerate(rows['name']):
         np.save(root / 'videos' / 'test' / name, synthetic_video(i, (77, 9, 41)[i], 40 + 2 * i, 30))   # sizes differ
     single, sharded = str(tmp_path / 'single'), str(tmp_path / 'sharded')
-    ic.inference_dataset(StubModel(), ['test'], single, checkpoint='stub', data_root=str(root))
+    ic.inference_dataset(StubModel(), ['test'], single, checkpoint='stub', data_root=str(root), shard='clips')
     _spawn(_dataset_by_videos_worker, str(root), sharded, world=world)
     assert sorted(os.listdir(single)) == sorted(os.listdir(sharded)) and len(os.listdir(single)) == 3
     for f in os.listdir(single):
@@ -147,9 +147,10 @@ GLOBAL_FRAMES = (77, 9, 41, 160, 8, 23, 95, 64, 130, 17)      # 10 / 2 / 6 / 20 
 
 @pytest.mark.parametrize('world', [2, 3, 8])
 def test_globally_sharded_inference_dataset_equals_single_process(tmp_path, golden_dir, world):
-    """shard='global' (the default for W > 1): whole videos to ranks longest-first by clip count, cross-video batches,
-    ONE exchange at the end, rank 0 writes: the JSON files are byte-identical to the single-process run at W = 2, 3
-    and 8 (W = 8 > the number of long videos: some ranks own one short video)."""
+    """shard='global' (the default): whole videos to ranks longest-first by clip count, cross-video batches, every rank
+    writes the files of its own videos as they finish, ONE exchange at the end: the JSON files are byte-identical to the
+    single-process video-at-a-time run (shard='clips') at W = 2, 3 and 8 (W = 8 > the number of long videos: some ranks
+    own one short video), and so are those of the single-process run of the same mode."""
     import pandas as pd
     from tests._stub import StubModel, synthetic_video
     from workoutdetector_amd import inference_count as ic
@@ -163,7 +164,7 @@ def test_globally_sharded_inference_dataset_equals_single_process(tmp_path, gold
     for i, name in enumerate(rows['name']):
         np.save(root / 'videos' / 'test' / name, synthetic_video(i, GLOBAL_FRAMES[i], 40 + 2 * (i % 3), 30))
     single, sharded = str(tmp_path / 'single'), str(tmp_path / 'sharded')
-    ic.inference_dataset(StubModel(), ['test'], single, checkpoint='stub', data_root=str(root))
+    ic.inference_dataset(StubModel(), ['test'], single, checkpoint='stub', data_root=str(root), shard='clips')
     os.makedirs(sharded)
     _spawn(_dataset_global_worker, str(root), sharded, 4, world=world)
     files = sorted(f for f in os.listdir(sharded) if f.endswith('.json'))
@@ -212,7 +213,7 @@ def test_global_sharding_with_a_rank_that_owns_no_video(tmp_path, golden_dir):
     for i, name in enumerate(rows['name']):
         np.save(root / 'videos' / 'test' / name, synthetic_video(i, (50, 19)[i], 40, 30))
     single, sharded = str(tmp_path / 'single'), str(tmp_path / 'sharded')
-    ic.inference_dataset(StubModel(), ['test'], single, checkpoint='stub', data_root=str(root))
+    ic.inference_dataset(StubModel(), ['test'], single, checkpoint='stub', data_root=str(root), shard='clips')
     _spawn(_dataset_global_anon_worker, str(root), sharded, world=3)
     for f in os.listdir(single):
         assert open(os.path.join(single, f)).read() == open(os.path.join(sharded, f)).read(), f

@@ -210,7 +210,7 @@ def test_two_rank_dataset_inference_with_real_engines(hip_lib, tmp_path, golden_
         np.save(root / 'videos' / 'test' / name, synthetic_video(60 + i, (90, 17, 41)[i], 96, 64, period=20))
     single, sharded = str(tmp_path / 'single'), str(tmp_path / 'sharded')
     eng = TsmEngine(num_class=12, max_clips=8, state_dict=make_state_dict(0, 12))
-    ic.inference_dataset(eng, ['test'], single, checkpoint='seed0', data_root=str(root), batch_clips=8)
+    ic.inference_dataset(eng, ['test'], single, checkpoint='seed0', data_root=str(root), batch_clips=8, shard='clips')
     eng.close()
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))

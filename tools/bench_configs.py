@@ -229,9 +229,10 @@ def config4_scaling(args):
             'lockstep_round_robin_efficiency': round(tdist.lockstep_efficiency(clips, world), 4),
             **({'rehearsal': True} if rehearsal else {}),
             'note': 'inference_dataset(shard="global"): whole videos to ranks longest-first, per rank pin + H2D of uint8 '
-                    'frames (prefetched one video ahead), fused HIP transform, engine in full cross-video batches of 32, '
-                    'no collective inside the loop, one D2H per rank, ONE exchange at the end (video table + padded '
-                    'logits), rank 0 writes the JSON files; time = max over ranks, barrier to last file'}), flush=True)
+                    'frames (prefetched two videos ahead), fused HIP transform, engine in full cross-video batches of 32, '
+                    'no collective inside the loop, every rank writes the JSON files of its own videos under the GPU work '
+                    'of the videos behind them (asynchronous D2H per video), ONE exchange at the end (video table + padded '
+                    'logits); time = max over ranks, barrier to last file'}), flush=True)
         shutil.rmtree(root, ignore_errors=True)
     eng.close()
     if world > 1:

@@ -273,13 +273,18 @@ def _staged_clips(model, st: StagedVideo, transform: TestTransform) -> Tuple[tor
         zero = transform(torch.zeros((1, 3) + st.hw, dtype=torch.float32, device=frames.device))
         frames = torch.cat([frames, zero], dim=0)                              # + the zero-padded tail frame
     # frame index of segment k of clip i: (start_i + 2k) / 2 - f_lo, or the shared zero frame past the end of the video.
-    # Built with tensor ops ON the frames' device: a host list -> device tensor copy would be a synchronous H2D that makes
-    # the host wait for everything queued on the stream (it was the per-video sync point of the dataset loop).
+    # A few hundred integers, computed on the host and sent with an ASYNCHRONOUS copy out of page-locked memory (the
+    # caching host allocator keeps the block until the copy has run).  Two forms this replaces: a host list -> device
+    # tensor constructor is a synchronous H2D that makes the host wait for everything queued on the stream (it was the
+    # per-video sync point of the dataset loop); arange / where / floor_divide on the device are six first-use loads of
+    # torch code objects, 30-100 ms each with the GPU idle (0.37 s at the head of a cold dataset job,
+    # profiles/r03_config4_gpu_gaps_before.txt).
     zi = frames.shape[0] - 1
-    dev_ = frames.device
-    first = CLIP_STEP * torch.arange(st.lo, st.hi, device=dev_, dtype=torch.int64)[:, None]
-    src = first + CLIP_STRIDE * torch.arange(NUM_SEGMENTS, device=dev_, dtype=torch.int64)[None, :]
-    idx = torch.where(src < st.total, src // CLIP_STRIDE - st.f_lo, torch.full_like(src, zi))
+    src = (CLIP_STEP * np.arange(st.lo, st.hi, dtype=np.int64)[:, None]
+           + CLIP_STRIDE * np.arange(NUM_SEGMENTS, dtype=np.int64)[None, :])
+    idx = torch.from_numpy(np.where(src < st.total, src // CLIP_STRIDE - st.f_lo, zi).astype(np.int64))
+    if frames.is_cuda:
+        idx = idx.pin_memory().to(frames.device, non_blocking=True)
     return frames, idx, hip_transform
 
 
@@ -302,10 +307,12 @@ def video_clip_logits(model, video_thwc_u8: torch.Tensor, transform: TestTransfo
 
 
 def prefetch_staged(model, videos: Iterable[Tuple[object, torch.Tensor]],
-                    clip_range_of: Optional[Callable[[torch.Tensor], Optional[Tuple[int, int]]]] = None
-                    ) -> Iterator[Tuple[object, StagedVideo]]:
-    """Double buffering over a stream of ``(key, uint8 video)``: while the caller computes on video i, a
-    worker thread reads / slices / pins video i+1 and copies it to the GPU on a side stream."""
+                    clip_range_of: Optional[Callable[[torch.Tensor], Optional[Tuple[int, int]]]] = None,
+                    depth: int = 1) -> Iterator[Tuple[object, StagedVideo]]:
+    """Prefetch over a stream of ``(key, uint8 video)``: while the caller computes on video i, ONE worker thread reads /
+    slices / pins videos i+1 .. i+depth in order and copies them to the GPU on a side stream.  ``depth`` = 1 is double
+    buffering; 2 lets the worker run a video ahead of that, so a video that takes longer to stage than its
+    predecessor took to compute does not stall the caller (the dataset loop; the pinned pool's three slots bound it)."""
     dev = _engine_device(model)
     side = torch.cuda.Stream(dev) if dev is not None and hasattr(model, 'packed_layout') else None
 
@@ -316,17 +323,19 @@ def prefetch_staged(model, videos: Iterable[Tuple[object, torch.Tensor]],
         return key, stage_video(model, vid, rng, side)
 
     it = iter(videos)
+    futs: Deque = deque()
     with ThreadPoolExecutor(max_workers=1) as pool:
-        try:
-            fut = pool.submit(work, next(it))
-        except StopIteration:
-            return
-        while fut is not None:
-            cur = fut.result()
-            try:
-                fut = pool.submit(work, next(it))
-            except StopIteration:
-                fut = None
+        def top_up():
+            while len(futs) < max(1, int(depth)):
+                try:
+                    futs.append(pool.submit(work, next(it)))
+                except StopIteration:
+                    return
+
+        top_up()
+        while futs:
+            cur = futs.popleft().result()
+            top_up()
             yield cur
 
 
@@ -423,23 +432,33 @@ def estimated_clips(item, frame_counter: Optional[Callable[[str], int]] = None) 
 
 
 class _ClipBatcher:
-    """Full ``batch_clips`` batches across video boundaries: clips of consecutive videos are queued and forwarded
-    whenever a whole batch is there (the ragged remainder once, at the end), and every logits row goes back to the
-    video it came from.  Clips are independent units (the temporal shift never leaves a clip) and the engine's
-    results do not depend on the batch a clip rides in, so this is bit-identical to per-video batches."""
+    """Full ``batch_clips`` batches across video boundaries: clips of consecutive videos are gathered into one
+    persistent batch buffer and forwarded whenever it is full (the ragged remainder once, at the end), and every
+    logits row goes back to the video it came from.  Clips are independent units (the temporal shift never leaves a
+    clip) and the engine's results do not depend on the batch a clip rides in, so this is bit-identical to per-video
+    batches.  The buffer is reused batch after batch: gather and forward are ordered on one stream."""
 
     def __init__(self, model, batch_clips: int):
         self.model, self.batch = model, int(batch_clips)
-        self.queue: List[Tuple[int, torch.Tensor, bool]] = []     # (video key, clips [n, 8, ...], packed device format)
+        self.buf: Optional[torch.Tensor] = None                   # [batch * 8, ...one frame]
+        self.hip: Optional[bool] = None
+        self.queue: List[Tuple[int, int]] = []                    # (video key, clips) of the rows in the buffer
         self.queued = 0
         self.rows: Dict[int, List[torch.Tensor]] = {}
 
     def add(self, key: int, frames: torch.Tensor, idx: torch.Tensor, hip_transform: bool) -> None:
         self.rows.setdefault(key, [])
+        if self.buf is None:
+            self.buf = torch.empty((self.batch * NUM_SEGMENTS,) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
+            self.hip = hip_transform
+        assert hip_transform == self.hip and frames.shape[1:] == self.buf.shape[1:] and frames.dtype == self.buf.dtype, \
+            'one job, one frame format'
         pos, n = 0, int(idx.shape[0])
         while pos < n:
             take = min(self.batch - self.queued, n - pos)
-            self.queue.append((key, frames[idx[pos:pos + take]], hip_transform))
+            torch.index_select(frames, 0, idx[pos:pos + take].reshape(-1),
+                               out=self.buf[self.queued * NUM_SEGMENTS:(self.queued + take) * NUM_SEGMENTS])
+            self.queue.append((key, take))
             self.queued += take
             pos += take
             if self.queued == self.batch:
@@ -448,19 +467,73 @@ class _ClipBatcher:
     def flush(self) -> None:
         if not self.queue:
             return
-        hip = self.queue[0][2]
-        assert all(q[2] == hip for q in self.queue)
-        clips = self.queue[0][1] if len(self.queue) == 1 else torch.cat([q[1] for q in self.queue], dim=0)
-        out = _forward_clips(self.model, clips, hip)
+        clips = self.buf[:self.queued * NUM_SEGMENTS].view((self.queued, NUM_SEGMENTS) + tuple(self.buf.shape[1:]))
+        out = _forward_clips(self.model, clips, bool(self.hip))
         pos = 0
-        for key, part, _ in self.queue:
-            self.rows[key].append(out[pos:pos + part.shape[0]])
-            pos += part.shape[0]
+        for key, n in self.queue:
+            self.rows[key].append(out[pos:pos + n])
+            pos += n
         self.queue, self.queued = [], 0
+
+    def complete(self, key: int) -> bool:
+        """Every clip of video ``key`` handed to ``add`` so far has been forwarded."""
+        return key in self.rows and all(k != key for k, _ in self.queue)
 
     def logits(self, key: int) -> torch.Tensor:
         parts = self.rows.pop(key)
         return torch.cat(parts, dim=0) if parts else torch.empty((0, getattr(self.model, 'num_class', 0)))
+
+
+class _ScoreWriter:
+    """Score files of finished videos, written WHILE the GPU works on the batches behind them: a finished video's logits
+    go to page-locked host memory with an asynchronous copy, and its JSON file is encoded once the event behind that copy
+    has completed -- polled between batches, never waited for before the end of the job.  (Encoding the whole dataset
+    after the last forward was a serial 0.5 s of the 6-s RepCount-val job; a writer THREAD fights the launch loop for the
+    interpreter lock.)  ``drain`` returns the host logits of every video in submission order."""
+
+    def __init__(self, out_dir: str, checkpoint: str, expected_rows: int):
+        self.out_dir, self.checkpoint, self.expected = out_dir, checkpoint, max(64, int(expected_rows))
+        self.host: Optional[torch.Tensor] = None      # one pinned block for the rank's rows (grown by whole blocks if the plan undercounted)
+        self.used = 0
+        self.pending: Deque = deque()                 # (item, host rows, frames, event)
+        self.done: List[torch.Tensor] = []
+
+    def _rows(self, n: int, ncls: int, pin: bool) -> torch.Tensor:
+        if self.host is None or self.used + n > self.host.shape[0] or self.host.shape[1] != ncls:
+            self.host = torch.empty((max(n, self.expected), ncls), dtype=torch.float32, pin_memory=pin)
+            self.used = 0
+        out = self.host[self.used:self.used + n]
+        self.used += n
+        return out
+
+    def submit(self, item, logits: torch.Tensor, n_frames: int) -> None:
+        assert logits.dim() == 2, 'per-video logits are [clips, classes]'
+        logits = logits.to(torch.float32)
+        if logits.is_cuda:
+            host = self._rows(int(logits.shape[0]), int(logits.shape[1]), True)
+            host.copy_(logits, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            host, ev = logits, None
+        self.pending.append((item, host, n_frames, ev))
+        self.poll()
+
+    def poll(self, wait: bool = False) -> None:
+        while self.pending:
+            item, host, n_frames, ev = self.pending[0]
+            if ev is not None:
+                if wait:
+                    ev.synchronize()
+                elif not ev.query():
+                    return
+            self.pending.popleft()
+            _write_score_json(self.out_dir, item, self.checkpoint, host, n_frames)
+            self.done.append(host)
+
+    def drain(self) -> List[torch.Tensor]:
+        self.poll(wait=True)
+        return self.done
 
 
 def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str, transform, reader, batch_clips: int,
@@ -474,11 +547,31 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
     dev = _engine_device(model)
     counts = [estimated_clips(it, frame_counter) for it in items]
     owner = tdist.plan_video_shards(counts, world)
-    mine = [v for v in range(len(items)) if owner[v] == rank]
+    # my videos, longest first: the page-locked staging buffers (three, grown to the largest video each has carried) then
+    # reach their final sizes on the first three videos, under those videos' own long GPU work; in dataset order every
+    # new longest video re-pinned a buffer mid-job (14 stalls of 30-150 ms with the GPU idle = 0.75 s of the 6.2-s
+    # RepCount-val job, profiles/r03_config4_gpu_gaps.txt)
+    mine = sorted((v for v in range(len(items)) if owner[v] == rank), key=lambda v: (-counts[v], v))
     batcher = _ClipBatcher(model, batch_clips)
+    writer = _ScoreWriter(out_dir, checkpoint, sum(counts[v] for v in mine) + 8 * len(mine))
     meta = torch.full((len(items), 4), -1, dtype=torch.int64)      # rows of MY videos: [video index, frames, clips, classes]
     direct: Dict[int, torch.Tensor] = {}
-    staged = prefetch_staged(model, ((v, (lambda p=items[v].video_path: reader(p))) for v in mine))
+    handed = 0                                                     # videos of ``mine`` already with the writer (in order)
+
+    def hand_over(final: bool) -> None:
+        # every rank writes the files of ITS videos (a node's ranks share the file system), each as soon as its last clip
+        # has been forwarded and its rows have reached the host -- under the GPU work of the videos behind it
+        nonlocal handed
+        while handed < seen:
+            v = mine[handed]
+            if v not in direct and not (final or batcher.complete(v)):
+                break
+            writer.submit(items[v], direct.pop(v) if v in direct else batcher.logits(v), int(meta[handed, 1]))
+            handed += 1
+        writer.poll()
+
+    seen = 0
+    staged = prefetch_staged(model, ((v, (lambda p=items[v].video_path: reader(p))) for v in mine), depth=2)
     for slot, (v, st) in enumerate(staged):
         n_clips = st.hi - st.lo
         meta[slot, :3] = torch.tensor([v, st.total, n_clips])
@@ -489,18 +582,14 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
             direct[v] = staged_clip_logits(model, st, transform, batch_clips)      # oversized: staged in pieces
         else:
             batcher.add(v, *_staged_clips(model, st, transform))
+        seen = slot + 1
+        hand_over(False)
     batcher.flush()
-    per_video = [direct[v] if v in direct else batcher.logits(v) for v in mine]
+    hand_over(True)
+    per_video = writer.drain()                                     # host rows of my videos, in ``mine`` order
     num_class = getattr(model, 'num_class', None) or (int(per_video[0].shape[1]) if per_video else 0)
-    local = (torch.cat([t.to(torch.float32).reshape(-1, num_class).cpu() for t in per_video], dim=0) if per_video
-             else torch.empty((0, num_class), dtype=torch.float32))      # one D2H per rank, after its last forward
-    # every rank writes the files of ITS videos (a node's ranks share the file system): the serial JSON encoding of the
-    # whole dataset on rank 0 after the exchange would be the Amdahl term of the job (0.5 s of a 0.7-s share at W = 8)
-    pos = 0
-    for slot, v in enumerate(mine):
-        n = int(meta[slot, 2])
-        _write_score_json(out_dir, items[v], checkpoint, local[pos:pos + n], int(meta[slot, 1]))
-        pos += n
+    local = (torch.cat([t.reshape(-1, num_class) for t in per_video], dim=0) if per_video
+             else torch.empty((0, num_class), dtype=torch.float32))
     if not tdist.collective_enabled():
         out, pos = {}, 0
         for slot, v in enumerate(mine):
@@ -537,17 +626,18 @@ def inference_dataset(model, splits: List[str], out_dir: str, checkpoint: str, p
     """Inference the RepCount dataset; one ``{video_name}.score.json`` per video with the reference's
     schema: video_name, model, input_shape, checkpoint, total_frames, ground_truth, action, scores.
 
-    Under ``torch.distributed``: ``shard='global'`` (the default with more than one rank: the dataset-throughput form,
-    SURVEY 8e "global clip index over a batch of videos ... gather once per many videos") assigns whole videos to
-    ranks by clip count, longest first, runs full cross-video batches with no collective inside the loop and
-    exchanges once at the end (``frame_counter(path) -> frames`` feeds the plan when neither rawframes nor ``.npy``
-    headers can; without it the annotation's last repetition frame does); ``shard='clips'`` splits the clips of
-    every video over the ranks (one all-gather per video: lowest latency for ONE stream, but every rank reads every
-    video); ``shard='videos'`` is the round-2 form, whole videos round-robin with an exchange per round of W videos
-    (each round lasts as long as its longest video)."""
+    ``shard='global'`` (the default: the dataset-throughput form, SURVEY 8e "global clip index over a batch of videos
+    ... gather once per many videos") assigns whole videos to ranks by clip count, longest first, runs full
+    cross-video batches with no collective inside the loop, writes every score file under the GPU work of the videos
+    behind it and, under ``torch.distributed``, exchanges once at the end (``frame_counter(path) -> frames`` feeds the
+    plan when neither rawframes nor ``.npy`` headers can; without it the annotation's last repetition frame does);
+    ``shard='clips'`` is the reference's loop shape, one video at a time, and under ``torch.distributed`` splits the
+    clips of every video over the ranks (one all-gather per video: lowest latency for ONE stream, but every rank reads
+    every video); ``shard='videos'`` is the round-2 form, whole videos round-robin with an exchange per round of W
+    videos (each round lasts as long as its longest video).  All three write identical files."""
     rank, _world = tdist.world_info()
     if shard is None:
-        shard = 'global' if _world > 1 else 'clips'
+        shard = 'global'
     if shard not in ('clips', 'videos', 'global'):
         raise ValueError("shard must be 'clips', 'videos' or 'global'")
     os.makedirs(out_dir, exist_ok=True)       # (every rank: with shard='global' each writes the files of its own videos)
