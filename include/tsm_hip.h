@@ -18,6 +18,7 @@
  *                          Bottleneck kept by TSM        workoutdetector/models/tsm.py:250-251,264-281
  *   tsm_maxpool3x3s2       base_model.maxpool
  *   tsm_head               avgpool -> fc -> view(-1,T,cls) -> mean(1)   tsm.py:411-419,165-174
+ *   tsm_gather_clips       the loop's clip windows: video[i:i + 16:2] for i in range(0, len(video), 8), zero-padded tail
  *   tsm_scores_to_states   per clip: to_softmax, first arg-max, score >= 0.5 ? class : -1
  *                          workoutdetector/utils/eval.py:153-164, utils/visualize.py:140-150
  *
@@ -44,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TSM_ABI_VERSION 4 /* 4: tsm_scores_to_states; tile codes lost the tail field; TSM_* variables read in tsm_create only */
+#define TSM_ABI_VERSION 5 /* 5: tsm_gather_clips; 4: tsm_scores_to_states; tile codes lost the tail field; TSM_* variables read in tsm_create only */
 
 typedef enum tsm_status {
   TSM_OK = 0,
@@ -192,6 +193,19 @@ int tsm_maxpool3x3s2(const float *x, float *y, int32_t n, int32_t hi, int32_t wi
  * (utils/inference_count.py:412-414); 1 scales to [0,1] first. */
 int tsm_preprocess(const void *frames, int32_t pixel, int32_t n, int32_t h, int32_t w, float *out,
                    int32_t out_layout, int32_t resize, int32_t crop, int32_t scale_255, void *stream);
+
+/* The clip iterator of the dataset loop on the GPU (device pointers), between tsm_preprocess and tsm_forward:
+ *   for i in range(0, len(video), 8): clip = video[i:i + 16:2], the tail zero-padded   utils/inference_count.py:411-414
+ * over TRANSFORMED frames: the buffer `frames` [n_frames, frame_bytes] (any tsm_preprocess layout; rows are opaque) holds
+ * every clip_stride-th frame of the video from source frame clip_stride * first_frame on, i.e. buffer frame j = source
+ * frame clip_stride * (first_frame + j).  out [n_clips, n_segment, frame_bytes]:
+ *   out[c][k] = source frame clip_step * (first_clip + c) + clip_stride * k   if that index < total_frames,
+ *               buffer frame pad_frame                                         otherwise (the transformed zero frame).
+ * Every index is validated on the host before the launch (TSM_ERR_INVALID_ARG, nothing launched): frame_bytes % 16 == 0,
+ * clip_step % clip_stride == 0, each clip starts inside the video, all frames it reads lie in the buffer. */
+int tsm_gather_clips(const void *frames, int64_t n_frames, int64_t frame_bytes, int64_t first_frame, int64_t total_frames,
+                     int64_t pad_frame, int64_t first_clip, int32_t n_clips, int32_t n_segment, int32_t clip_step,
+                     int32_t clip_stride, void *out, void *stream);
 
 /* feat [n_clips*T, hw, c] NHWC -> logits [n_clips, num_class]; fc_w [num_class, c], fc_b. */
 int tsm_head(const float *feat, const float *fc_w, const float *fc_b, float *logits,

@@ -285,3 +285,39 @@ def test_bench_names_the_kernels_rocprof_prints():
         assert ('tsm::' + name) in seen[mode], (tile, dtype, cmid, name)
     assert bench.kernel_of('ws+conv3', 'bf16', 64) == ('conv3x3_ws_kernel<true>', True)
     assert bench.kernel_of('64x64/splitK', 'f32', 512)[0] == 'conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, true>'
+
+
+def test_prefetch_pieces_covers_every_clip_once_and_survives_failures():
+    """prefetch_pieces (the dataset loop's stager): every video comes as consecutive clip ranges of at most piece_clips
+    that cover its clips exactly once, the last one flagged; a reader that raises surfaces in the consumer; a consumer
+    that walks away does not leave the worker blocked on a full queue."""
+    import threading
+    import time
+    from tests._stub import StubModel, synthetic_video
+    from workoutdetector_amd import inference_count as ic
+    lens = [77, 8, 1, 130, 16, 0]
+    vids = [(k, (lambda i=i, n=n: torch.from_numpy(synthetic_video(i, n, 20, 18)) if n else torch.zeros((0, 20, 18, 3), dtype=torch.uint8)))
+            for k, (i, n) in enumerate(enumerate(lens))]
+    seen = {}
+    for key, st, last in ic.prefetch_pieces(StubModel(), vids, piece_clips=4, depth=2):
+        a = seen.setdefault(key, dict(next=0, last=False, total=st.total))
+        assert not a['last'] and st.lo == a['next'] and st.hi - st.lo <= 4 and st.total == lens[key]
+        a['next'], a['last'] = st.hi, last
+    assert sorted(seen) == list(range(len(lens)))
+    for k, n in enumerate(lens):
+        assert seen[k]['last'] and seen[k]['next'] == len(ic.clip_starts(n)), (k, seen[k])
+
+    def bad():
+        raise OSError('no such video')
+    with pytest.raises(OSError, match='no such video'):
+        for _ in ic.prefetch_pieces(StubModel(), [(0, vids[0][1]), (1, bad)], piece_clips=4):
+            pass
+    # early exit: the generator is closed with the queue full; the worker must come home
+    before = {t.name for t in threading.enumerate()}
+    gen = ic.prefetch_pieces(StubModel(), vids, piece_clips=1, depth=1)
+    next(gen)
+    gen.close()
+    deadline = time.time() + 5
+    while any(t.name == 'tsm-stage' and t.is_alive() for t in threading.enumerate()) and time.time() < deadline:
+        time.sleep(0.05)
+    assert not any(t.name == 'tsm-stage' and t.is_alive() for t in threading.enumerate()), before

@@ -72,3 +72,42 @@ def test_pixel_pair_layouts_of_the_bf16_formats(hip_lib, crop, resize):
     assert torch.equal(g[:, :, :, 0].reshape(2, crop, pairs * 2, 4)[:, :, :crop, :3], want.to(torch.bfloat16).float())
     err = (val[:, :, :crop, :3] - want).abs()
     assert bool((err <= want.abs() * 2.0 ** -16 + 1e-30).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('layout_name', ['f32', 'bf16x3', 'nchw'])
+def test_gather_clips_equals_the_reference_windows(hip_lib, layout_name):
+    """tsm_gather_clips == the reference loop's windows (utils/inference_count.py:411-414: vid[i:i + 16:2] for i in
+    range(0, len(vid), 8), the tail padded) on transformed frames, bit for bit against torch.index_select over the same
+    buffer: whole videos and clip sub-ranges whose buffer starts mid-video, totals that end inside a window, on a step
+    boundary and one frame past it; and the host-side validation refuses every range that would read outside the buffer."""
+    import torch
+    from workoutdetector_amd import _lib, engine
+    from workoutdetector_amd import inference_count as ic
+    g = torch.Generator().manual_seed(5)
+    layout = {'f32': _lib.LAYOUT_NTHWC4, 'bf16x3': _lib.LAYOUT_NTHWC8S, 'nchw': _lib.LAYOUT_NTCHW}[layout_name]
+    for total, (lo, hi) in [(77, (0, 10)), (77, (3, 7)), (64, (0, 8)), (65, (5, 9)), (9, (0, 2)), (16, (1, 2)), (1, (0, 1))]:
+        video = torch.randint(0, 256, (total, 36, 52, 3), dtype=torch.uint8, generator=g)
+        starts = ic.clip_starts(total)
+        assert hi <= len(starts)
+        f_lo = starts[lo] // 2
+        f_hi = min((starts[hi - 1] + 16) // 2, (total + 1) // 2)
+        even = torch.cat([video[0::2][f_lo:f_hi], torch.zeros((1, 36, 52, 3), dtype=torch.uint8)]).cuda()
+        frames = engine.preprocess_frames(even, resize=32, crop=24, layout=layout)
+        src = 8 * torch.arange(lo, hi)[:, None] + 2 * torch.arange(8)[None, :]
+        idx = torch.where(src < total, src // 2 - f_lo, torch.full_like(src, frames.shape[0] - 1))
+        want = frames[idx.cuda()]
+        got = engine.gather_clips(frames, f_lo, total, lo, hi - lo)
+        assert got.shape == want.shape and torch.equal(got, want), (total, lo, hi)
+        # into a slice of a larger buffer, as the batcher does
+        buf = torch.full((3 + (hi - lo) + 2, 8) + tuple(frames.shape[1:]), -7.0, device='cuda')
+        engine.gather_clips(frames, f_lo, total, lo, hi - lo, out=buf[3:3 + hi - lo])
+        assert torch.equal(buf[3:3 + hi - lo], want) and bool((buf[:3] == -7).all()) and bool((buf[3 + hi - lo:] == -7).all())
+    # refusals: nothing may be launched for a range that leaves the buffer
+    frames = torch.zeros((6, 24, 24, 4), device='cuda')
+    for kw in [dict(first_frame=0, total_frames=77, first_clip=0, n_clips=2),      # needs 12 even frames, 6 in the buffer
+               dict(first_frame=4, total_frames=77, first_clip=0, n_clips=1),      # clip 0 starts before the buffer
+               dict(first_frame=0, total_frames=8, first_clip=1, n_clips=1),       # clip 1 starts at frame 8 = past the end
+               dict(first_frame=0, total_frames=9, first_clip=0, n_clips=1, pad_frame=6)]:   # pad frame outside
+        with pytest.raises(_lib.TsmError):
+            engine.gather_clips(frames, **kw)

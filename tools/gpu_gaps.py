@@ -19,7 +19,7 @@ def main(path, min_gap_us=100.0):
     busy_end, busy = rows[0][0], 0.0
     gaps = []
     for s, e, n in rows:
-        key = n.split('(')[0].replace('void ', '').replace('tsm::', '')[:60]
+        key = n.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').replace('tsm::', '')[:90]
         fam[key] += (e - s) / 1e3
         if s > busy_end:
             gaps.append(((s - busy_end) / 1e3, key, (s - rows[0][0]) / 1e6))
@@ -39,10 +39,10 @@ def main(path, min_gap_us=100.0):
         after[k][0] += 1
         after[k][1] += g
     for k, (n, t) in sorted(after.items(), key=lambda kv: -kv[1][1])[:8]:
-        print(f'  long gaps ended by {k:60s} {n:5d} x, {t / 1e3:8.1f} ms')
+        print(f'  long gaps ended by {k:90s} {n:5d} x, {t / 1e3:8.1f} ms')
     print('busy time by kernel family:')
     for k, t in sorted(fam.items(), key=lambda kv: -kv[1])[:12]:
-        print(f'  {k:60s} {t / 1e3:9.1f} ms')
+        print(f'  {k:90s} {t / 1e3:9.1f} ms')
 
 
 if __name__ == '__main__':

@@ -1107,6 +1107,23 @@ int tsm_preprocess(const void *frames, int32_t pixel, int32_t n, int32_t h, int3
   return TSM_OK;
 }
 
+int tsm_gather_clips(const void *frames, int64_t n_frames, int64_t frame_bytes, int64_t first_frame, int64_t total_frames,
+                     int64_t pad_frame, int64_t first_clip, int32_t n_clips, int32_t n_segment, int32_t clip_step,
+                     int32_t clip_stride, void *out, void *stream) {
+  if (!frames || !out) return fail(nullptr, TSM_ERR_INVALID_ARG, "gather_clips: null pointer");
+  tsm::GatherParams p{};
+  p.frames = frames; p.out = out; p.n_frames = n_frames; p.frame_bytes = frame_bytes; p.first_frame = first_frame;
+  p.total_frames = total_frames; p.first_clip = first_clip; p.pad_frame = pad_frame; p.n_clips = n_clips;
+  p.n_segment = n_segment; p.clip_step = clip_step; p.clip_stride = clip_stride;
+  hipError_t st = tsm::launch_gather_clips(p, static_cast<hipStream_t>(stream));
+  if (st != hipSuccess)
+    return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,
+                st == hipErrorInvalidValue ? std::string("gather_clips: a clip of the range reads outside the frame buffer "
+                                                         "(or frame_bytes is not a multiple of 16, or more than 65535 rows)")
+                                           : std::string("gather_clips: ") + hipGetErrorString(st));
+  return TSM_OK;
+}
+
 int tsm_head(const float *feat, const float *fc_w, const float *fc_b, float *logits, int32_t n_clips,
              int32_t n_segment, int32_t hw, int32_t c, int32_t num_class, void *stream) {
   if (!feat || !fc_w || !fc_b || !logits || n_clips <= 0 || n_segment <= 0 || hw <= 0 || c <= 0 || num_class <= 0)

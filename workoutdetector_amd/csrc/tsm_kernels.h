@@ -145,6 +145,16 @@ struct PreprocParams {
 };
 hipError_t launch_preprocess(const PreprocParams &p, hipStream_t s);
 
+// Clips out of a buffer of transformed frames (see gather_clips_kernel).  Buffer frame j holds source frame
+// clip_stride * (first_frame + j); pad_frame is the buffer's frame for positions past the end of the video.
+struct GatherParams {
+  const void *frames;
+  void *out;
+  int64_t n_frames, frame_bytes, first_frame, total_frames, first_clip, pad_frame;
+  int n_clips, n_segment, clip_step, clip_stride;
+};
+hipError_t launch_gather_clips(const GatherParams &p, hipStream_t s);
+
 hipError_t launch_maxpool3x3s2(const float *x, float *y, int n, int hi, int wi, int c, int prec,
                                hipStream_t s);
 hipError_t launch_temporal_shift(const float *x, float *y, int64_t n_frames, int n_segment,

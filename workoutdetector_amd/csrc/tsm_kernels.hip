@@ -3853,6 +3853,52 @@ hipError_t launch_preprocess(const PreprocParams &p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gather_clips: the clip iterator of the dataset loop (utils/inference_count.py:411-414, video[i:i + 16:2] with a
+// zero-padded tail) over TRANSFORMED frames that sit in a device buffer: out[c][k] = frame of source index
+// step * (first_clip + c) + stride * k, the buffer's pad frame where that index is past the video's end.  Frames are
+// opaque rows of frame_bytes (any packed layout); 16-byte copies, four in flight per thread.  HBM-bound and tiny
+// next to the forward (a batch of 32 clips moves 2 x 205 MB: 0.1 ms) -- it exists so that the loop's only device work
+// between two forwards is this library's: torch's index_select costs two first-use code-object loads (4 + 150 ms with
+// the GPU idle at the head of every cold dataset job, profiles/r03_config4_gpu_gaps_pieces.txt).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_clips_kernel(const GatherParams p) {
+  const int row = blockIdx.y;                       // (clip, segment) of the output
+  const int c = row / p.n_segment, k = row - c * p.n_segment;
+  const int64_t src_frame = (int64_t)p.clip_step * (p.first_clip + c) + (int64_t)p.clip_stride * k;
+  const int64_t j = src_frame < p.total_frames ? src_frame / p.clip_stride - p.first_frame : p.pad_frame;
+  const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const char *>(p.frames) + j * p.frame_bytes);
+  uint4 *dst = reinterpret_cast<uint4 *>(static_cast<char *>(p.out) + (int64_t)row * p.frame_bytes);
+  const int64_t n16 = p.frame_bytes / 16;
+  for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 1024) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * 256 < n16) v[u] = src[i + u * 256];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * 256 < n16) dst[i + u * 256] = v[u];
+  }
+}
+
+hipError_t launch_gather_clips(const GatherParams &p, hipStream_t s) {
+  if (!p.frames || !p.out || p.n_frames <= 0 || p.frame_bytes <= 0 || p.frame_bytes % 16 != 0 || p.n_clips <= 0 ||
+      p.n_segment <= 0 || p.clip_step <= 0 || p.clip_stride <= 0 || p.clip_step % p.clip_stride != 0 ||
+      p.first_clip < 0 || p.first_frame < 0 || p.total_frames <= 0 || (int64_t)p.n_clips * p.n_segment > 65535)
+    return hipErrorInvalidValue;
+  // every index the kernel will form, checked here: the first and the last in-video position of the range, and the pad frame
+  const int64_t lo = (int64_t)p.clip_step * p.first_clip;
+  const int64_t hi = (int64_t)p.clip_step * (p.first_clip + p.n_clips - 1) + (int64_t)p.clip_stride * (p.n_segment - 1);
+  if (lo >= p.total_frames) return hipErrorInvalidValue;                       // a clip starts inside its video
+  const int64_t last = (hi < p.total_frames ? hi : p.total_frames - 1) / p.clip_stride - p.first_frame;
+  if (lo / p.clip_stride - p.first_frame < 0 || last >= p.n_frames) return hipErrorInvalidValue;
+  if (hi >= p.total_frames && (p.pad_frame < 0 || p.pad_frame >= p.n_frames)) return hipErrorInvalidValue;
+  const int64_t n16 = p.frame_bytes / 16;
+  const unsigned gx = (unsigned)((n16 + 1023) / 1024 < 64 ? (n16 + 1023) / 1024 : 64);
+  hipLaunchKernelGGL(gather_clips_kernel, dim3(gx, (unsigned)(p.n_clips * p.n_segment)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // maxpool 3x3 stride 2 pad 1, NHWC; one thread per (output pixel, channel group).
 // ---------------------------------------------------------------------------------------------
 template <int FMT>

@@ -407,6 +407,31 @@ def preprocess_frames(frames, resize: int = 256, crop: int = 224, scale_255: boo
     return out
 
 
+def gather_clips(frames, first_frame: int, total_frames: int, first_clip: int, n_clips: int, out=None,
+                 n_segment: int = 8, clip_step: int = 8, clip_stride: int = 2, pad_frame: Optional[int] = None):
+    """The clip windows of the dataset loop on the GPU (``tsm_gather_clips``; the reference's ``vid[i:i + 16:2]`` for
+    ``i in range(0, len(vid), 8)``, tail zero-padded: utils/inference_count.py:411-414) over transformed frames.
+
+    frames: CUDA tensor [n, ...] holding every ``clip_stride``-th frame of the video from source frame
+    ``clip_stride * first_frame`` on (any ``preprocess_frames`` layout); ``pad_frame`` (default: the last frame of the
+    buffer) stands in for positions past ``total_frames``.  Returns ``out`` [n_clips, n_segment, ...] (allocated when
+    None; else any contiguous CUDA tensor of that many bytes, e.g. a slice of a persistent batch buffer)."""
+    import torch
+    if not frames.is_cuda or not frames.is_contiguous():
+        raise ValueError('frames must be a contiguous CUDA tensor')
+    n = int(frames.shape[0])
+    frame_bytes = int(frames[0].numel()) * frames.element_size()
+    if out is None:
+        out = torch.empty((n_clips, n_segment) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
+    if (not out.is_cuda or not out.is_contiguous() or out.device != frames.device
+            or out.numel() * out.element_size() != n_clips * n_segment * frame_bytes):
+        raise ValueError('out must be a contiguous CUDA tensor of n_clips * n_segment frames on the frames\' device')
+    _lib.check(_lib.load().tsm_gather_clips(frames.data_ptr(), n, frame_bytes, int(first_frame), int(total_frames),
+                                            n - 1 if pad_frame is None else int(pad_frame), int(first_clip), int(n_clips),
+                                            n_segment, clip_step, clip_stride, out.data_ptr(), _stream(frames)))
+    return out
+
+
 def scores_to_states(logits, threshold: float = 0.5, softmax: bool = True, return_top: bool = False):
     """K9 on the GPU: CUDA float32 logits [n, num_class] -> int32 states [n] (utils/eval.py:153-164: softmax, first
     arg-max, class id if its score >= threshold else -1) and optionally the winning score.  Enqueues on torch's

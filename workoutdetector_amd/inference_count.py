@@ -38,6 +38,7 @@ import contextlib
 import json
 import os
 import os.path as osp
+import queue
 import threading
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
@@ -60,6 +61,7 @@ CLIP_STEP = 8
 # holds several GB of even frames; beyond this bound the clip range is processed in pieces (each piece re-stages the
 # 8-frame overlap it needs), so pinned host memory stays <= 3 pool slots x 1.25 x this and device memory proportional.
 MAX_STAGE_BYTES = 1 << 30
+PIECE_CLIPS = 64              # clips per staged piece of the dataset loop (two batches of 32: 58 MB of 360 x 206 frames)
 
 
 # ---- video sources -------------------------------------------------------------------------------------
@@ -245,15 +247,16 @@ def staged_clip_logits(model, st: StagedVideo, transform: TestTransform, batch_c
                                             transform, batch_clips))
         return torch.cat(parts, dim=0)
     frames, idx, hip_transform = _staged_clips(model, st, transform)
-    out = [_forward_clips(model, frames[idx[b:b + batch_clips]], hip_transform)
-           for b in range(0, idx.shape[0], batch_clips)]
+    n = int(idx.shape[0])
+    out = [_forward_clips(model, _gather(frames, idx, st, b, min(b + batch_clips, n)), hip_transform)
+           for b in range(0, n, batch_clips)]
     return torch.cat(out, dim=0).to(torch.float32).cpu()
 
 
 def _staged_clips(model, st: StagedVideo, transform: TestTransform) -> Tuple[torch.Tensor, torch.Tensor, bool]:
-    """Transformed frames of a staged clip range (each frame once), the [n_clips, 8] frame indices of its clips
-    (the zero-padded tail points at one shared zero frame), and whether the frames are in the engine's packed
-    device format (HIP transform) rather than float32 [n,3,224,224]."""
+    """Transformed frames of a staged clip range (each frame once), the [n_clips, 8] frame indices of its clips as a
+    HOST tensor (the zero-padded tail points at one shared zero frame, the last of the buffer), and whether the frames
+    are in the engine's packed device format (HIP transform) rather than float32 [n,3,224,224]."""
     dev = _engine_device(model)
     hip_transform = st.on_device and isinstance(transform, TestTransform)
     if hip_transform:
@@ -272,20 +275,33 @@ def _staged_clips(model, st: StagedVideo, transform: TestTransform) -> Tuple[tor
         frames = transform(even.permute(0, 3, 1, 2).to(torch.float32))        # [n_even, 3, 224, 224]
         zero = transform(torch.zeros((1, 3) + st.hw, dtype=torch.float32, device=frames.device))
         frames = torch.cat([frames, zero], dim=0)                              # + the zero-padded tail frame
-    # frame index of segment k of clip i: (start_i + 2k) / 2 - f_lo, or the shared zero frame past the end of the video.
-    # A few hundred integers, computed on the host and sent with an ASYNCHRONOUS copy out of page-locked memory (the
-    # caching host allocator keeps the block until the copy has run).  Two forms this replaces: a host list -> device
-    # tensor constructor is a synchronous H2D that makes the host wait for everything queued on the stream (it was the
-    # per-video sync point of the dataset loop); arange / where / floor_divide on the device are six first-use loads of
-    # torch code objects, 30-100 ms each with the GPU idle (0.37 s at the head of a cold dataset job,
-    # profiles/r03_config4_gpu_gaps_before.txt).
+    # frame index of segment k of clip i: (start_i + 2k) / 2 - f_lo, or the shared zero frame past the end of the video:
+    # a few hundred integers, kept on the HOST -- on the GPU the windows are cut by tsm_gather_clips from (f_lo, total,
+    # first clip) alone (see _gather); only the torch fallback uploads them.
     zi = frames.shape[0] - 1
     src = (CLIP_STEP * np.arange(st.lo, st.hi, dtype=np.int64)[:, None]
            + CLIP_STRIDE * np.arange(NUM_SEGMENTS, dtype=np.int64)[None, :])
     idx = torch.from_numpy(np.where(src < st.total, src // CLIP_STRIDE - st.f_lo, zi).astype(np.int64))
-    if frames.is_cuda:
-        idx = idx.pin_memory().to(frames.device, non_blocking=True)
     return frames, idx, hip_transform
+
+
+def _gather(frames: torch.Tensor, idx: torch.Tensor, st: Optional[StagedVideo], a: int, b: int,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Clips ``a .. b`` of a staged range as [b - a, 8, ...one frame] (into ``out`` -- [(b - a) * 8, ...] -- if given).
+    Device frames: ``tsm_gather_clips`` cuts the windows from the range's (first frame, total frames, first clip);
+    nothing is uploaded and no torch kernel runs (``index_select`` / advanced indexing cost two first-use code-object
+    loads, 4 + 150 ms with the GPU idle at the head of a cold job).  Host frames, or no staged range: torch."""
+    n = b - a
+    if st is not None and frames.is_cuda and frames.is_contiguous() and (frames[0].numel() * frames.element_size()) % 16 == 0:
+        from .engine import gather_clips
+        got = gather_clips(frames, st.f_lo, st.total, st.lo + a, n, out=out, n_segment=NUM_SEGMENTS, clip_step=CLIP_STEP,
+                           clip_stride=CLIP_STRIDE)
+        return got.view((n, NUM_SEGMENTS) + tuple(frames.shape[1:]))
+    sel = idx[a:b].reshape(-1)
+    if frames.is_cuda:
+        sel = sel.pin_memory().to(frames.device, non_blocking=True)
+    got = torch.index_select(frames, 0, sel) if out is None else torch.index_select(frames, 0, sel, out=out)
+    return got.view((n, NUM_SEGMENTS) + tuple(frames.shape[1:]))
 
 
 def _forward_clips(model, clips: torch.Tensor, hip_transform: bool) -> torch.Tensor:
@@ -337,6 +353,66 @@ def prefetch_staged(model, videos: Iterable[Tuple[object, torch.Tensor]],
             cur = futs.popleft().result()
             top_up()
             yield cur
+
+
+def prefetch_pieces(model, videos: Iterable[Tuple[object, torch.Tensor]], piece_clips: int = PIECE_CLIPS,
+                    depth: int = 3) -> Iterator[Tuple[object, StagedVideo, bool]]:
+    """``(key, staged piece, is the video's last piece)`` over a stream of ``(key, uint8 video or reader)``: one worker
+    thread reads each video once and stages it in pieces of ``piece_clips`` consecutive clips (fewer if the frames
+    are so large that a piece would pass ``MAX_STAGE_BYTES``), up to ``depth`` pieces ahead of the caller.  Against whole
+    videos: the first kernel of a job starts after one piece (a few ms of pinning and copying instead of the whole
+    first video: 0.14 s, which every rank of a multi-GPU job pays on a job N times shorter), the page-locked buffers
+    and the device blocks have ONE size for the whole job (no re-pinning when a longer video arrives), and the device
+    footprint is a piece, not a video."""
+    dev = _engine_device(model)
+    side = torch.cuda.Stream(dev) if dev is not None and hasattr(model, 'packed_layout') else None
+    out: 'queue.Queue' = queue.Queue(maxsize=max(1, int(depth)))
+    stop = threading.Event()
+
+    def put(x) -> bool:
+        while not stop.is_set():
+            try:
+                out.put(x, timeout=0.05)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def produce():
+        try:
+            for key, vid in videos:
+                vid = vid() if callable(vid) else vid
+                n = len(clip_starts(int(vid.shape[0])))
+                per_frame = max(1, int(vid[0].numel())) if int(vid.shape[0]) else 1
+                fit = (MAX_STAGE_BYTES // per_frame - CLIP_SPAN // CLIP_STRIDE) // (CLIP_STEP // CLIP_STRIDE)
+                step = max(1, min(int(piece_clips), fit))
+                if n == 0 and not put((key, stage_video(model, vid, (0, 0), side), True)):
+                    return
+                for a in range(0, n, step):
+                    b = min(a + step, n)
+                    if not put((key, stage_video(model, vid, (a, b), side), b == n)):
+                        return
+            put(None)
+        except BaseException as e:      # surfaces in the caller
+            put(e)
+
+    worker = threading.Thread(target=produce, name='tsm-stage', daemon=True)
+    worker.start()                      # (at the call, not at the first next(): the caller's own setup overlaps the first piece)
+
+    def drain():
+        try:
+            while True:
+                item = out.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            worker.join(timeout=5.0)
+
+    return drain()
 
 
 def _rank_clip_range(total_frames: int) -> Optional[Tuple[int, int]]:
@@ -446,7 +522,10 @@ class _ClipBatcher:
         self.queued = 0
         self.rows: Dict[int, List[torch.Tensor]] = {}
 
-    def add(self, key: int, frames: torch.Tensor, idx: torch.Tensor, hip_transform: bool) -> None:
+    def add(self, key: int, frames: torch.Tensor, idx: torch.Tensor, hip_transform: bool,
+            st: Optional[StagedVideo] = None) -> None:
+        """Queue every clip of a staged range: ``frames`` / ``idx`` / ``hip_transform`` as ``_staged_clips`` returns
+        them, ``st`` the range itself (lets device frames be cut by the HIP gather; None: torch ``index_select``)."""
         self.rows.setdefault(key, [])
         if self.buf is None:
             self.buf = torch.empty((self.batch * NUM_SEGMENTS,) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
@@ -456,8 +535,8 @@ class _ClipBatcher:
         pos, n = 0, int(idx.shape[0])
         while pos < n:
             take = min(self.batch - self.queued, n - pos)
-            torch.index_select(frames, 0, idx[pos:pos + take].reshape(-1),
-                               out=self.buf[self.queued * NUM_SEGMENTS:(self.queued + take) * NUM_SEGMENTS])
+            _gather(frames, idx, st, pos, pos + take,
+                    out=self.buf[self.queued * NUM_SEGMENTS:(self.queued + take) * NUM_SEGMENTS])
             self.queue.append((key, take))
             self.queued += take
             pos += take
@@ -479,6 +558,10 @@ class _ClipBatcher:
         """Every clip of video ``key`` handed to ``add`` so far has been forwarded."""
         return key in self.rows and all(k != key for k, _ in self.queue)
 
+    def parts(self, key: int) -> List[torch.Tensor]:
+        """The logits rows of video ``key``, in clip order, as the slices of the batches they rode in."""
+        return self.rows.pop(key)
+
     def logits(self, key: int) -> torch.Tensor:
         parts = self.rows.pop(key)
         return torch.cat(parts, dim=0) if parts else torch.empty((0, getattr(self.model, 'num_class', 0)))
@@ -491,14 +574,20 @@ class _ScoreWriter:
     after the last forward was a serial 0.5 s of the 6-s RepCount-val job; a writer THREAD fights the launch loop for the
     interpreter lock.)  ``drain`` returns the host logits of every video in submission order."""
 
-    def __init__(self, out_dir: str, checkpoint: str, expected_rows: int):
+    def __init__(self, out_dir: str, checkpoint: str, expected_rows: int, num_class: Optional[int] = None,
+                 pin: bool = False):
         self.out_dir, self.checkpoint, self.expected = out_dir, checkpoint, max(64, int(expected_rows))
-        self.host: Optional[torch.Tensor] = None      # one pinned block for the rank's rows (grown by whole blocks if the plan undercounted)
+        # one pinned block for the rank's rows (grown by whole blocks if the plan undercounted); with a known class count
+        # it is pinned NOW, while the first piece is still being staged, not between two forwards
+        self.host: Optional[torch.Tensor] = (torch.empty((self.expected, int(num_class)), dtype=torch.float32, pin_memory=True)
+                                             if pin and num_class else None)
         self.used = 0
         self.pending: Deque = deque()                 # (item, host rows, frames, event)
         self.done: List[torch.Tensor] = []
 
     def _rows(self, n: int, ncls: int, pin: bool) -> torch.Tensor:
+        if n == 0:
+            return torch.empty((0, ncls), dtype=torch.float32)
         if self.host is None or self.used + n > self.host.shape[0] or self.host.shape[1] != ncls:
             self.host = torch.empty((max(n, self.expected), ncls), dtype=torch.float32, pin_memory=pin)
             self.used = 0
@@ -506,16 +595,22 @@ class _ScoreWriter:
         self.used += n
         return out
 
-    def submit(self, item, logits: torch.Tensor, n_frames: int) -> None:
-        assert logits.dim() == 2, 'per-video logits are [clips, classes]'
-        logits = logits.to(torch.float32)
-        if logits.is_cuda:
-            host = self._rows(int(logits.shape[0]), int(logits.shape[1]), True)
-            host.copy_(logits, non_blocking=True)
+    def submit(self, item, parts: Sequence[torch.Tensor], n_frames: int) -> None:
+        """``parts``: the video's rows as [n_i, classes] slices in clip order (no concatenation on the device: each slice is
+        one small asynchronous copy into its place in the host block)."""
+        parts = [p.to(torch.float32) for p in parts if p.shape[0]]
+        n = sum(int(p.shape[0]) for p in parts)
+        ncls = int(parts[0].shape[1]) if parts else 0
+        cuda = any(p.is_cuda for p in parts)
+        host = self._rows(n, ncls, cuda)
+        pos = 0
+        for p in parts:
+            host[pos:pos + p.shape[0]].copy_(p, non_blocking=True)
+            pos += int(p.shape[0])
+        ev = None
+        if cuda:
             ev = torch.cuda.Event()
             ev.record()
-        else:
-            host, ev = logits, None
         self.pending.append((item, host, n_frames, ev))
         self.poll()
 
@@ -542,47 +637,42 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
     each to the least-loaded rank (``distributed.plan_video_shards``) -- every rank then decodes and runs ITS videos
     with full cross-video batches and NO collective inside the loop, and the job ends with one exchange: an
     all-gather of the per-video [index, frames, clips] table and ONE padded all-gather of the per-clip logits
-    ``[clips_on_rank, num_class]`` (returned per video on every rank).  Each rank writes the JSON files of its own videos."""
+    ``[clips_on_rank, num_class]`` (returned per video on every rank).  Each rank writes the JSON files of its own videos
+    while its GPU works on the videos behind them."""
     rank, world = tdist.world_info()
     dev = _engine_device(model)
     counts = [estimated_clips(it, frame_counter) for it in items]
     owner = tdist.plan_video_shards(counts, world)
-    # my videos, longest first: the page-locked staging buffers (three, grown to the largest video each has carried) then
-    # reach their final sizes on the first three videos, under those videos' own long GPU work; in dataset order every
-    # new longest video re-pinned a buffer mid-job (14 stalls of 30-150 ms with the GPU idle = 0.75 s of the 6.2-s
-    # RepCount-val job, profiles/r03_config4_gpu_gaps.txt)
-    mine = sorted((v for v in range(len(items)) if owner[v] == rank), key=lambda v: (-counts[v], v))
+    mine = [v for v in range(len(items)) if owner[v] == rank]
     batcher = _ClipBatcher(model, batch_clips)
-    writer = _ScoreWriter(out_dir, checkpoint, sum(counts[v] for v in mine) + 8 * len(mine))
+    # (the stager's worker starts on the first video here, before the host-side setup below)
+    pieces = prefetch_pieces(model, ((v, (lambda p=items[v].video_path: reader(p))) for v in mine))
+    writer = _ScoreWriter(out_dir, checkpoint, sum(counts[v] for v in mine) + 8 * len(mine),
+                          getattr(model, 'num_class', None), pin=dev is not None)
     meta = torch.full((len(items), 4), -1, dtype=torch.int64)      # rows of MY videos: [video index, frames, clips, classes]
-    direct: Dict[int, torch.Tensor] = {}
-    handed = 0                                                     # videos of ``mine`` already with the writer (in order)
+    slot_of = {v: i for i, v in enumerate(mine)}
+    whole = 0                                                      # videos of ``mine`` whose last piece has been queued
+    handed = 0                                                     # ... already with the writer (in order)
 
     def hand_over(final: bool) -> None:
         # every rank writes the files of ITS videos (a node's ranks share the file system), each as soon as its last clip
         # has been forwarded and its rows have reached the host -- under the GPU work of the videos behind it
         nonlocal handed
-        while handed < seen:
-            v = mine[handed]
-            if v not in direct and not (final or batcher.complete(v)):
-                break
-            writer.submit(items[v], direct.pop(v) if v in direct else batcher.logits(v), int(meta[handed, 1]))
+        while handed < whole and (final or batcher.complete(mine[handed])):
+            writer.submit(items[mine[handed]], batcher.parts(mine[handed]), int(meta[handed, 1]))
             handed += 1
         writer.poll()
 
-    seen = 0
-    staged = prefetch_staged(model, ((v, (lambda p=items[v].video_path: reader(p))) for v in mine), depth=2)
-    for slot, (v, st) in enumerate(staged):
-        n_clips = st.hi - st.lo
-        meta[slot, :3] = torch.tensor([v, st.total, n_clips])
-        if n_clips == 0:
-            batcher.rows.setdefault(v, [])
-        elif (not st.on_device and dev is not None and hasattr(model, 'packed_layout')
-                and int(st.frames.numel()) > MAX_STAGE_BYTES):
-            direct[v] = staged_clip_logits(model, st, transform, batch_clips)      # oversized: staged in pieces
+    for v, st, last in pieces:
+        slot = slot_of[v]
+        done = max(0, int(meta[slot, 2]))
+        meta[slot, :3] = torch.tensor([v, st.total, done + st.hi - st.lo])
+        if st.hi > st.lo:
+            batcher.add(v, *_staged_clips(model, st, transform), st=st)
         else:
-            batcher.add(v, *_staged_clips(model, st, transform))
-        seen = slot + 1
+            batcher.rows.setdefault(v, [])
+        if last:
+            whole = slot + 1
         hand_over(False)
     batcher.flush()
     hand_over(True)
