@@ -321,3 +321,26 @@ def test_prefetch_pieces_covers_every_clip_once_and_survives_failures():
     while any(t.name == 'tsm-stage' and t.is_alive() for t in threading.enumerate()) and time.time() < deadline:
         time.sleep(0.05)
     assert not any(t.name == 'tsm-stage' and t.is_alive() for t in threading.enumerate()), before
+
+
+def test_gpu_gaps_tool_accounts_for_overlap_and_idle_time(tmp_path, capsys):
+    """tools/gpu_gaps.py (the config-4 idle-time analysis behind profiles/r03_config4_gpu_gaps*.txt): busy time is the
+    UNION of the kernels' intervals (concurrent kernels on two streams are not counted twice) and every idle interval
+    is attributed to the kernel that ended it."""
+    import csv
+    import runpy
+    trace = tmp_path / 'trace.csv'
+    rows = [(0, 1_000_000, 'void tsm::preprocess_kernel<unsigned char>(tsm::PreprocParams)'),
+            (500_000, 1_500_000, 'void tsm::gather_clips_kernel(tsm::GatherParams)'),                 # overlaps the first
+            (1_500_010, 2_500_000, 'void tsm::conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, true>(tsm::ConvParams)'),
+            (4_500_000, 5_000_000, 'void at::native::(anonymous namespace)::indexSelectSmallIndex<float, long>(x)')]  # 2 ms idle before it
+    with open(trace, 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['Kernel_Name', 'Start_Timestamp', 'End_Timestamp'])
+        for s, e, n in rows:
+            w.writerow([n, s, e])
+    mod = runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'gpu_gaps.py'))
+    mod['main'](str(trace), 1000.0)
+    out = capsys.readouterr().out
+    assert 'span 5.0 ms, busy 3.0 ms (0.600), idle 2.0 ms in 2 gaps' in out, out
+    assert 'gaps >= 1000 us: 1, 2.0 ms' in out and 'ended by at::native::indexSelectSmallIndex<float, long>' in out, out

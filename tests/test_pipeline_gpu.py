@@ -236,3 +236,32 @@ def test_oversized_videos_are_staged_in_pieces(probe_engine, monkeypatch):
     assert tuple(whole.shape) == (42, 12) and torch.equal(whole, pieces)
     part = ic.video_clip_logits(eng, vid, tf, clip_range=(5, 31), batch_clips=16)   # a rank's block of a sharded video
     assert torch.equal(part, whole[5:31])
+
+
+@pytest.mark.gpu
+def test_dataset_loop_pieces_shrink_to_the_staging_bound(probe_engine, tmp_path, golden_dir, monkeypatch):
+    """The dataset loop (shard='global') stages videos in pieces; a piece shrinks until it fits MAX_STAGE_BYTES.  With a
+    bound of 12 even frames a piece is ONE clip (8 even frames + the pad frame): score files byte-identical to the
+    video-at-a-time path with whole-video staging, i.e. piece boundaries (every clip is one), the overlap of
+    neighbouring pieces' frames and the cross-video batcher change no bit."""
+    import pandas as pd
+    from workoutdetector_amd import inference_count as ic
+    from workoutdetector_amd.repcount import CLASSES
+    eng, _ = probe_engine
+    anno = pd.read_csv(f'{golden_dir}/repcount_annotation.csv', index_col=0)
+    rows = anno[(anno['split'] == 'test') & anno['class_'].isin(CLASSES)].head(3).copy()
+    rows['name'] = [n.replace('.mp4', '.npy') for n in rows['name']]
+    root = tmp_path / 'RepCount'
+    (root / 'videos' / 'test').mkdir(parents=True)
+    rows.to_csv(root / 'annotation.csv')
+    for i, (name, frames) in enumerate(zip(rows['name'], (77, 130, 9))):
+        np.save(root / 'videos' / 'test' / name, synthetic_video(20 + i, frames, 90, 52, period=24))
+    whole, pieces = str(tmp_path / 'whole'), str(tmp_path / 'pieces')
+    ic.inference_dataset(eng, ['test'], whole, checkpoint='seed0', data_root=str(root), batch_clips=8, shard='clips')
+    monkeypatch.setattr(ic, 'MAX_STAGE_BYTES', 12 * 90 * 52 * 3)
+    got = ic.inference_dataset(eng, ['test'], pieces, checkpoint='seed0', data_root=str(root), batch_clips=8)
+    files = sorted(os.listdir(whole))
+    assert files == sorted(os.listdir(pieces)) and len(files) == 3
+    for f in files:
+        assert open(os.path.join(whole, f)).read() == open(os.path.join(pieces, f)).read(), f
+    assert sorted(int(v.shape[0]) for v in got.values()) == [2, 10, 17]
