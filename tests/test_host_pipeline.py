@@ -344,3 +344,23 @@ def test_gpu_gaps_tool_accounts_for_overlap_and_idle_time(tmp_path, capsys):
     out = capsys.readouterr().out
     assert 'span 5.0 ms, busy 3.0 ms (0.600), idle 2.0 ms in 2 gaps' in out, out
     assert 'gaps >= 1000 us: 1, 2.0 ms' in out and 'ended by at::native::indexSelectSmallIndex<float, long>' in out, out
+
+
+def test_a_failing_forward_ends_the_dataset_job_without_a_stuck_stager(tiny_dataset, tmp_path):
+    """An exception inside the dataset loop (here: the session's second forward) surfaces to the caller and the stager
+    thread, which may be blocked on its full queue at that moment, goes home."""
+    import threading
+    import time
+
+    class Flaky(StubModel):
+        def run(self, output_names, feed):
+            if self.calls >= 1:
+                raise RuntimeError('device lost')
+            return super().run(output_names, feed)
+
+    with pytest.raises(RuntimeError, match='device lost'):
+        ic.inference_dataset(Flaky(), ['test'], str(tmp_path / 'out'), checkpoint='stub', data_root=tiny_dataset, batch_clips=4)
+    deadline = time.time() + 5
+    while any(t.name == 'tsm-stage' and t.is_alive() for t in threading.enumerate()) and time.time() < deadline:
+        time.sleep(0.05)
+    assert not any(t.name == 'tsm-stage' and t.is_alive() for t in threading.enumerate())

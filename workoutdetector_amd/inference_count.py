@@ -663,17 +663,20 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
             handed += 1
         writer.poll()
 
-    for v, st, last in pieces:
-        slot = slot_of[v]
-        done = max(0, int(meta[slot, 2]))
-        meta[slot, :3] = torch.tensor([v, st.total, done + st.hi - st.lo])
-        if st.hi > st.lo:
-            batcher.add(v, *_staged_clips(model, st, transform), st=st)
-        else:
-            batcher.rows.setdefault(v, [])
-        if last:
-            whole = slot + 1
-        hand_over(False)
+    try:
+        for v, st, last in pieces:
+            slot = slot_of[v]
+            done = max(0, int(meta[slot, 2]))
+            meta[slot, :3] = torch.tensor([v, st.total, done + st.hi - st.lo])
+            if st.hi > st.lo:
+                batcher.add(v, *_staged_clips(model, st, transform), st=st)
+            else:
+                batcher.rows.setdefault(v, [])
+            if last:
+                whole = slot + 1
+            hand_over(False)
+    finally:
+        pieces.close()       # (a failure in the loop must not leave the stager blocked on its full queue)
     batcher.flush()
     hand_over(True)
     per_video = writer.drain()                                     # host rows of my videos, in ``mine`` order
