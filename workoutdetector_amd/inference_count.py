@@ -323,12 +323,10 @@ def video_clip_logits(model, video_thwc_u8: torch.Tensor, transform: TestTransfo
 
 
 def prefetch_staged(model, videos: Iterable[Tuple[object, torch.Tensor]],
-                    clip_range_of: Optional[Callable[[torch.Tensor], Optional[Tuple[int, int]]]] = None,
-                    depth: int = 1) -> Iterator[Tuple[object, StagedVideo]]:
-    """Prefetch over a stream of ``(key, uint8 video)``: while the caller computes on video i, ONE worker thread reads /
-    slices / pins videos i+1 .. i+depth in order and copies them to the GPU on a side stream.  ``depth`` = 1 is double
-    buffering; 2 lets the worker run a video ahead of that, so a video that takes longer to stage than its
-    predecessor took to compute does not stall the caller (the dataset loop; the pinned pool's three slots bound it)."""
+                    clip_range_of: Optional[Callable[[torch.Tensor], Optional[Tuple[int, int]]]] = None
+                    ) -> Iterator[Tuple[object, StagedVideo]]:
+    """Double buffering over a stream of ``(key, uint8 video)``: while the caller computes on video i, a
+    worker thread reads / slices / pins video i+1 and copies it to the GPU on a side stream."""
     dev = _engine_device(model)
     side = torch.cuda.Stream(dev) if dev is not None and hasattr(model, 'packed_layout') else None
 
@@ -339,80 +337,84 @@ def prefetch_staged(model, videos: Iterable[Tuple[object, torch.Tensor]],
         return key, stage_video(model, vid, rng, side)
 
     it = iter(videos)
-    futs: Deque = deque()
     with ThreadPoolExecutor(max_workers=1) as pool:
-        def top_up():
-            while len(futs) < max(1, int(depth)):
-                try:
-                    futs.append(pool.submit(work, next(it)))
-                except StopIteration:
-                    return
-
-        top_up()
-        while futs:
-            cur = futs.popleft().result()
-            top_up()
+        try:
+            fut = pool.submit(work, next(it))
+        except StopIteration:
+            return
+        while fut is not None:
+            cur = fut.result()
+            try:
+                fut = pool.submit(work, next(it))
+            except StopIteration:
+                fut = None
             yield cur
 
 
-def prefetch_pieces(model, videos: Iterable[Tuple[object, torch.Tensor]], piece_clips: int = PIECE_CLIPS,
-                    depth: int = 3) -> Iterator[Tuple[object, StagedVideo, bool]]:
-    """``(key, staged piece, is the video's last piece)`` over a stream of ``(key, uint8 video or reader)``: one worker
-    thread reads each video once and stages it in pieces of ``piece_clips`` consecutive clips (fewer if the frames
-    are so large that a piece would pass ``MAX_STAGE_BYTES``), up to ``depth`` pieces ahead of the caller.  Against whole
-    videos: the first kernel of a job starts after one piece (a few ms of pinning and copying instead of the whole
-    first video: 0.14 s, which every rank of a multi-GPU job pays on a job N times shorter), the page-locked buffers
-    and the device blocks have ONE size for the whole job (no re-pinning when a longer video arrives), and the device
-    footprint is a piece, not a video."""
-    dev = _engine_device(model)
-    side = torch.cuda.Stream(dev) if dev is not None and hasattr(model, 'packed_layout') else None
-    out: 'queue.Queue' = queue.Queue(maxsize=max(1, int(depth)))
-    stop = threading.Event()
+class prefetch_pieces:
+    """Iterator of ``(key, staged piece, is the video's last piece)`` over a stream of ``(key, uint8 video or reader)``:
+    one worker thread, started here, reads each video once and stages it in pieces of ``piece_clips`` consecutive clips
+    (fewer if the frames are so large that a piece would pass ``MAX_STAGE_BYTES``), up to ``depth`` pieces ahead of the
+    caller.  Against whole videos: the first kernel of a job starts after one piece (a few ms of pinning and copying
+    instead of the whole first video: 0.14 s, which every rank of a multi-GPU job pays on a job N times shorter), the
+    page-locked buffers and the device blocks have ONE size for the whole job (no re-pinning when a longer video
+    arrives), and the device footprint is a piece, not a video.  ``close()`` (also at exhaustion) sends the worker
+    home even if it is blocked on the full queue."""
 
-    def put(x) -> bool:
-        while not stop.is_set():
+    def __init__(self, model, videos: Iterable[Tuple[object, torch.Tensor]], piece_clips: int = PIECE_CLIPS,
+                 depth: int = 3):
+        dev = _engine_device(model)
+        self._model, self._videos, self._piece = model, videos, int(piece_clips)
+        self._side = torch.cuda.Stream(dev) if dev is not None and hasattr(model, 'packed_layout') else None
+        self._out: 'queue.Queue' = queue.Queue(maxsize=max(1, int(depth)))
+        self._stop = threading.Event()
+        self._worker = threading.Thread(target=self._produce, name='tsm-stage', daemon=True)
+        self._worker.start()       # (now, not at the first next(): the caller's own setup overlaps the first piece)
+
+    def _put(self, x) -> bool:
+        while not self._stop.is_set():
             try:
-                out.put(x, timeout=0.05)
+                self._out.put(x, timeout=0.05)
                 return True
             except queue.Full:
                 pass
         return False
 
-    def produce():
+    def _produce(self) -> None:
         try:
-            for key, vid in videos:
+            for key, vid in self._videos:
                 vid = vid() if callable(vid) else vid
                 n = len(clip_starts(int(vid.shape[0])))
                 per_frame = max(1, int(vid[0].numel())) if int(vid.shape[0]) else 1
                 fit = (MAX_STAGE_BYTES // per_frame - CLIP_SPAN // CLIP_STRIDE) // (CLIP_STEP // CLIP_STRIDE)
-                step = max(1, min(int(piece_clips), fit))
-                if n == 0 and not put((key, stage_video(model, vid, (0, 0), side), True)):
+                step = max(1, min(self._piece, fit))
+                if n == 0 and not self._put((key, stage_video(self._model, vid, (0, 0), self._side), True)):
                     return
                 for a in range(0, n, step):
                     b = min(a + step, n)
-                    if not put((key, stage_video(model, vid, (a, b), side), b == n)):
+                    if not self._put((key, stage_video(self._model, vid, (a, b), self._side), b == n)):
                         return
-            put(None)
+            self._put(None)
         except BaseException as e:      # surfaces in the caller
-            put(e)
+            self._put(e)
 
-    worker = threading.Thread(target=produce, name='tsm-stage', daemon=True)
-    worker.start()                      # (at the call, not at the first next(): the caller's own setup overlaps the first piece)
+    def __iter__(self):
+        return self
 
-    def drain():
-        try:
-            while True:
-                item = out.get()
-                if item is None:
-                    return
-                if isinstance(item, BaseException):
-                    raise item
-                yield item
-        finally:
-            stop.set()
-            worker.join(timeout=5.0)
+    def __next__(self) -> Tuple[object, StagedVideo, bool]:
+        if self._stop.is_set():
+            raise StopIteration
+        item = self._out.get()
+        if item is None or isinstance(item, BaseException):
+            self.close()
+            if item is None:
+                raise StopIteration
+            raise item
+        return item
 
-    return drain()
+    def close(self) -> None:
+        self._stop.set()
+        self._worker.join(timeout=5.0)
 
 
 def _rank_clip_range(total_frames: int) -> Optional[Tuple[int, int]]:
@@ -644,9 +646,18 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
     counts = [estimated_clips(it, frame_counter) for it in items]
     owner = tdist.plan_video_shards(counts, world)
     mine = [v for v in range(len(items)) if owner[v] == rank]
-    batcher = _ClipBatcher(model, batch_clips)
     # (the stager's worker starts on the first video here, before the host-side setup below)
     pieces = prefetch_pieces(model, ((v, (lambda p=items[v].video_path: reader(p))) for v in mine))
+    try:
+        return _run_global(model, items, mine, counts, pieces, out_dir, checkpoint, transform, batch_clips, dev, rank, world)
+    finally:
+        pieces.close()       # (a failure anywhere below must not leave the stager blocked on its full queue)
+
+
+def _run_global(model, items: list, mine: List[int], counts: List[int], pieces, out_dir: str, checkpoint: str, transform,
+                batch_clips: int, dev, rank: int, world: int) -> Dict[str, torch.Tensor]:
+    """The loop, the score files and the final exchange of ``_inference_dataset_global``."""
+    batcher = _ClipBatcher(model, batch_clips)
     writer = _ScoreWriter(out_dir, checkpoint, sum(counts[v] for v in mine) + 8 * len(mine),
                           getattr(model, 'num_class', None), pin=dev is not None)
     meta = torch.full((len(items), 4), -1, dtype=torch.int64)      # rows of MY videos: [video index, frames, clips, classes]
@@ -663,20 +674,17 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
             handed += 1
         writer.poll()
 
-    try:
-        for v, st, last in pieces:
-            slot = slot_of[v]
-            done = max(0, int(meta[slot, 2]))
-            meta[slot, :3] = torch.tensor([v, st.total, done + st.hi - st.lo])
-            if st.hi > st.lo:
-                batcher.add(v, *_staged_clips(model, st, transform), st=st)
-            else:
-                batcher.rows.setdefault(v, [])
-            if last:
-                whole = slot + 1
-            hand_over(False)
-    finally:
-        pieces.close()       # (a failure in the loop must not leave the stager blocked on its full queue)
+    for v, st, last in pieces:
+        slot = slot_of[v]
+        done = max(0, int(meta[slot, 2]))
+        meta[slot, :3] = torch.tensor([v, st.total, done + st.hi - st.lo])
+        if st.hi > st.lo:
+            batcher.add(v, *_staged_clips(model, st, transform), st=st)
+        else:
+            batcher.rows.setdefault(v, [])
+        if last:
+            whole = slot + 1
+        hand_over(False)
     batcher.flush()
     hand_over(True)
     per_video = writer.drain()                                     # host rows of my videos, in ``mine`` order
