@@ -179,6 +179,8 @@ def kernel_of(tile, dtype, cmid):
         return 'conv23_fused_kernel<%d, %s>' % (cmid, 'true' if dtype == 'bf16x3' else 'false'), True
     if main == '256x256':
         return 'conv_bf16_256_kernel<3, false, false, false>', False
+    if main == '256x256p':
+        return 'conv_bf16_256p_kernel<3, false, false, false>', False
     waves = '1, 1' if main == '32x32' else '4, 2' if main.endswith('w8') else '2, 2'
     prec_id = {'f32': 0, 'bf16x3': 1, 'bf16': 2}[dtype]
     # template arguments: BM, BN, WGM, WGN, KS, SHIFT, RES, PREC, DUAL, SEG (fp32 long-K layers accumulate K in segments)

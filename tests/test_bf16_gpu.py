@@ -101,6 +101,8 @@ def test_tile_choice_is_bitwise_neutral_in_bf16_modes(hip_lib, sd0, monkeypatch,
                       # the 8-wave LDS-DMA kernel wherever it applies (bf16, Cout % 256 == 0): every conv3 (residual
                       # arm; K-concatenated downsample arm in the first block of a stage), conv2 / conv1 of layer3-4
                       ('256x256', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '256x256'}),
+                      # ... and its persistent form (same arms incl. the K-concatenated downsample one; K >= 128, Cout <= 2048)
+                      ('256x256p', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': '256x256p'}),
                       # the weight-stationary 3x3 kernel where it applies (bf16, 64 -> 64 channels: conv2 of layer1)
                       ('ws', {'TSM_AUTOTUNE': '0', 'TSM_CONV_TILE': 'ws'})]:
         for k in ('TSM_AUTOTUNE', 'TSM_CONV_TILE'):
@@ -164,12 +166,19 @@ def test_fused_stem_maxpool_equals_separate_kernels_bitwise(hip_lib, sd0, monkey
     (4, 16, 16, 256, 1024, 1, 1, True, 0, True),   # layer3 conv3 + residual: four n-tiles
     (3, 9, 7, 128, 512, 1, 1, True, 0, True),      # layer2 conv3 + residual, ragged (189 rows), K = 128
     (2, 8, 8, 512, 2048, 1, 1, False, 0, True),    # layer4 conv3 + residual, no ReLU
+    (96, 16, 16, 256, 1024, 1, 1, True, 0, True),  # 384 tiles on 256 workgroups: the persistent form's second tile, ragged tail of the grid
+    (40, 14, 14, 256, 256, 3, 1, True, 0, False),  # 3x3, 31 m-tiles (ragged last one) x 1: fewer tiles than workgroups
+    (208, 16, 16, 128, 512, 1, 1, True, 0, True),  # K = 128 (two K-tiles: every refill of a tile's last K-tile is the NEXT tile's), 416 tiles
+    (72, 16, 16, 1024, 256, 1, 1, True, 8, False), # shifted conv1, 72 tiles; clips of 8 frames cross tile boundaries
+    (200, 12, 12, 128, 256, 3, 1, False, 0, False),# 3x3, K = 1152, 113 m-tiles, no ReLU
+    (300, 16, 16, 64, 256, 3, 1, True, 0, False),  # 300 tiles (K = 576: odd K-tile count -> the buffer parity flips from tile to tile)
 ])
 def test_lds_dma_256_tile_equals_the_128_tiles_bitwise(hip_lib, monkeypatch, n, hi, wi, cin, cout, k, stride, relu, shiftT,
                                                        use_res):
-    """conv_bf16_256_kernel (256 x 256 tile, 8 waves, LDS-DMA staging, counted vmcnt) against conv_igemm's bf16 tiles
-    through the per-op entry point: same k order per output -> same bits; and both against the fp32 oracle at the
-    bf16 mode's tolerance."""
+    """conv_bf16_256_kernel (256 x 256 tile, 8 waves, LDS-DMA staging, counted vmcnt) and its persistent form
+    conv_bf16_256p_kernel (flat K pipeline across a workgroup's tiles, transposed product, register epilogue) against
+    conv_igemm's bf16 tiles through the per-op entry point: same k order per output -> same bits; and against the
+    bf16-storage oracle at the bf16 mode's per-op bar."""
     from workoutdetector_amd.engine import conv_bn_act_nhwc
     g = torch.Generator().manual_seed(7000 + cin + cout + k + hi)
     x = torch.randn(n, cin, hi, wi, generator=g)
@@ -179,12 +188,15 @@ def test_lds_dma_256_tile_equals_the_128_tiles_bitwise(hip_lib, monkeypatch, n, 
     ho, wo = (hi + 2 * pad - k) // stride + 1, (wi + 2 * pad - k) // stride + 1
     res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
     outs = {}
-    for tile in ('256x256', '128x128', '64x64'):
+    persistent = cin * k * k >= 128        # conv_bf16_256p_kernel needs two K-tiles per tile
+    for tile in ('256x256', '128x128', '64x64') + (('256x256p',) if persistent else ()):
         monkeypatch.setenv('TSM_CONV_TILE', tile)
         outs[tile] = conv_bn_act_nhwc(_nhwc(x).cuda(), w.cuda(), *[b.cuda() for b in bn], stride=stride, relu=relu,
                                       residual=None if res is None else _nhwc(res).cuda(),
                                       shift_segments=shiftT, fold_div=8, dtype='bf16').cpu()
     assert torch.equal(outs['256x256'], outs['128x128']) and torch.equal(outs['256x256'], outs['64x64'])
+    if persistent:      # the same pipeline run persistently over a workgroup's tiles, register epilogue
+        assert torch.equal(outs['256x256p'], outs['256x256'])
     xin = tsm_oracle.temporal_shift(x, shiftT, 8) if shiftT else x
     want = tsm_oracle.conv_bn_act_bf16(xin, w, bn, stride, k // 2, relu, res)
     assert_bf16_op(_nchw(outs['256x256']).numpy(), want.numpy(), what='256x256 bf16')

@@ -216,6 +216,8 @@ def test_c_program_runs_a_forward(hip_lib, tmp_path):
     ('bf16+fused', 3, 8, 90, 70, 12, 1e-2),
     ('bf16+256x256', 2, 8, 64, 64, 12, 1e-2),
     ('bf16+256x256', 3, 8, 90, 70, 12, 1e-2),
+    ('bf16+256x256p', 2, 8, 64, 64, 12, 1e-2),   # round 3: the persistent form of that tile
+    ('bf16+256x256p', 3, 8, 90, 70, 12, 1e-2),
 ])
 def test_unusual_configurations_against_oracle(hip_lib, monkeypatch, capsys, dtype, t, div, h, w, ncls, rtol):
     """Segment counts, shift_div, class counts and aspect ratios other than the headline's, vs the CPU oracle."""

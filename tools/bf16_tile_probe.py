@@ -17,7 +17,7 @@ sd = make_state_dict(0, 12)
 x = torch.randn(B, T, 3, S, S, device='cuda')
 macs = {r['name']: r['macs'] for r in layer_table(S, S)}
 res = {}
-for tile in ('auto', '128x128', '128x64', '256x256', 'ws'):
+for tile in ('auto', '128x128', '256x256', '256x256p', 'ws'):
     os.environ.pop('TSM_CONV_TILE', None)
     os.environ.pop('TSM_AUTOTUNE', None)
     if tile != 'auto':

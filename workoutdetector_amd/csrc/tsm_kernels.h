@@ -50,10 +50,11 @@ enum ConvTile {
   kTile128x128w8 = 5,  // 128x128 on 8 waves (512 threads): same LDS as kTile128x128, twice the waves per SIMD
   kTile256x256 = 6,    // conv_bf16_256_kernel: bf16 only, 8 waves, one workgroup per CU, operands by LDS-DMA
   kTileWs = 7,       // conv3x3_ws[128]_kernel: bf16 3x3 s1 p1 with C = Cout = 64 / 128, weights resident in registers, input patch by LDS-DMA
-  kNumTiles = 8
+  kTile256x256p = 8, // conv_bf16_256p_kernel: kTile256x256's pipeline run persistently over a workgroup's tiles (K >= 128, Cout <= 2048)
+  kNumTiles = 9
 };
 void conv_tile_dims(int tile, int *bm, int *bn);
-// "128x128" | "128x64" | "64x64" | "32x32" | "128x128w8" | "256x256" | "ws" -> ConvTile (kTileAuto for anything else).
+// "128x128" | "128x64" | "64x64" | "32x32" | "128x128w8" | "256x256" | "256x256p" | "ws" -> ConvTile (kTileAuto for anything else).
 int conv_tile_from_name(const char *name);
 // Is `tile` usable for this problem (Cout divisibility)?
 bool conv_tile_valid(const ConvParams &p, int tile);

@@ -803,7 +803,7 @@ void conv_tile_shape(const ConvParams &p, int *bm, int *bn) {
 int conv_tile_from_name(const char *name) {
   if (!name) return kTileAuto;
   static const struct { const char *n; int t; } names[] = {{"128x128", kTile128x128}, {"128x64", kTile128x64},
-      {"64x64", kTile64x64}, {"32x32", kTile32x32}, {"128x128w8", kTile128x128w8}, {"256x256", kTile256x256}, {"ws", kTileWs}};
+      {"64x64", kTile64x64}, {"32x32", kTile32x32}, {"128x128w8", kTile128x128w8}, {"256x256", kTile256x256}, {"ws", kTileWs}, {"256x256p", kTile256x256p}};
   for (const auto &e : names)
     if (strcmp(name, e.n) == 0) return e.t;
   return kTileAuto;
@@ -819,17 +819,21 @@ bool conv_tile_valid(const ConvParams &p, int tile) {
     case kTile256x256:   // (ks is checked at launch: the stem has C == 4 and never qualifies)
       return p.prec == kPrecBf16 && p.Cout % 256 == 0 && p.C % 64 == 0 && !(p.res && p.x2) &&
              (!p.x2 || (p.K1 % 64 == 0 && p.C2 % 64 == 0));
+    case kTile256x256p:   // (ks is checked at launch; at least two K-tiles, the bias of all channels in LDS)
+      return p.prec == kPrecBf16 && p.Cout % 256 == 0 && p.Cout <= 2048 && p.C % 64 == 0 && p.Kp >= 128 && !(p.res && p.x2) &&
+             (!p.x2 || (p.K1 % 64 == 0 && p.C2 % 64 == 0));
     case kTileWs: return conv3x3_ws_valid(p) || conv3x3_ws128_valid(p) || conv1x1_ws_valid(p) || conv1x1_wsn_valid(p);   // (pad singles out 3x3 / 1x1)
     default: return false;
   }
 }
 
 void conv_tile_dims(int tile, int *bm, int *bn) {
-  *bm = (tile == kTile256x256 || tile == kTileWs) ? 256 : tile == kTile32x32 ? 32 : (tile == kTile64x64 ? 64 : 128);
-  *bn = tile == kTile256x256 ? 256 : tile == kTile32x32 ? 32 : ((tile == kTile128x128 || tile == kTile128x128w8) ? 128 : 64);
+  *bm = (tile == kTile256x256 || tile == kTile256x256p || tile == kTileWs) ? 256 : tile == kTile32x32 ? 32 : (tile == kTile64x64 ? 64 : 128);
+  *bn = (tile == kTile256x256 || tile == kTile256x256p) ? 256 : tile == kTile32x32 ? 32 : ((tile == kTile128x128 || tile == kTile128x128w8) ? 128 : 64);
 }
 
 static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s);
+static hipError_t launch_conv_bf16_256p(ConvParams p, int ks, hipStream_t s);
 static hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s);
 static hipError_t launch_conv1x1_ws(const ConvParams &p, hipStream_t s);
 static hipError_t launch_conv1x1_wsn(const ConvParams &p, hipStream_t s);
@@ -845,6 +849,10 @@ static hipError_t launch_conv_ks(const ConvParams &p_in, hipStream_t s) {
   }
   if (p.tile == kTile256x256) {
     if constexpr (KS != 7) return launch_conv_bf16_256(p, KS, s);
+    else return hipErrorInvalidValue;
+  }
+  if (p.tile == kTile256x256p) {
+    if constexpr (KS != 7) return launch_conv_bf16_256p(p, KS, s);
     else return hipErrorInvalidValue;
   }
   if (p.tile == kTileWs) {
@@ -1166,6 +1174,312 @@ bool conv_bf16_256_valid(const ConvParams &p, int ks) {
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_bf16_256p: conv_bf16_256's K pipeline run PERSISTENTLY over the tiles of a workgroup, without ever draining.
+//
+// Why: conv_bf16_256 is one 128-KB workgroup per CU, so nothing overlaps a tile's prologue (the first operands' HBM
+// latency, 2-3 us) or its epilogue (accumulators through LDS, residual loads, stores) -- and with short K that is a
+// third of a tile (K = 256: four K-tiles = 3.4 us of MFMA per 17-us tile; the 1x1 launches of layer3/4 sit at 3.0-4.3
+// TB/s and 0.29-0.44 of the MFMA peak: neither roofline).  Here
+//   * the K-tile sequence is FLAT across tiles: the refills the last two K-tiles of tile s issue ("K-tile kt + 1,
+//     kt + 2") are the first K-tiles of tile s + 1, staged from that tile's loader state (two sets of lane offsets and
+//     descriptors, current / next); the four-half-operands-in-flight schedule, its counted waits, the staggered wave
+//     groups and the barriers are conv_bf16_256's, unchanged, and run from the first K-tile of the first tile to the
+//     last K-tile of the last;
+//   * the epilogue touches no LDS, so it can sit between two K-tiles while the next tile's operands land: the product
+//     is TRANSPOSED (A = weights, B = pixels: the fragment formats are symmetric, the products of an output enter its
+//     accumulator in the same k order -> same bits), a lane then holds 4-channel runs of ONE pixel, and bias +
+//     residual + ReLU + bf16 + v_permlane32_swap give 16-byte stores straight from registers (conv3x3_ws's epilogue);
+//     the bias of all Cout channels sits in LDS behind the two buffers;
+//   * the 16 stores of an epilogue are younger than the operands the next K-tile waits for: its two counted waits
+//     are vmcnt(8 + 16) instead of vmcnt(8) (vector-memory operations retire in order; a vmcnt(8) there would wait
+//     for the stores' completion).
+// Needs at least two K-tiles per tile (K >= 128: "kt + 2" must not skip a tile) and Cout <= 2048 (the bias in LDS).
+// Bit-identical to conv_bf16_256 and to conv_igemm's bf16 tiles; the tuner picks per layer.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kLds256pBytes = 131072 + 8192;
+
+template <int KS, bool SHIFT, bool DUAL> struct Tile256State {
+  unsigned a_off[2], b_off[2];
+  unsigned a_mask[KS == 3 ? 2 : 1];
+  unsigned a_offp[SHIFT ? 2 : 1], a_offm[SHIFT ? 2 : 1];
+  unsigned a_off2[DUAL ? 2 : 1];
+  int m0, n0;
+  // (the operand windows as plain pointers + sizes: the host pass cannot hold __amdgpu_buffer_rsrc_t in a struct; the
+  //  descriptors are rebuilt where they are used -- scalar moves)
+  const char *pa, *pb, *pa2;
+  int sza, sza2;
+};
+
+template <int KS, bool SHIFT, bool RES = false, bool DUAL = false>
+__global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams p) {
+  static_assert(KS == 1 || KS == 3, "1x1 (optionally temporally shifted) and 3x3");
+  static_assert(!(RES || DUAL) || (KS == 1 && !SHIFT), "residual / K-concatenated second source: plain 1x1 convs (conv3)");
+  static_assert(!(RES && DUAL), "the fused conv3 + downsample GEMM has no residual");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 buffers x 64 KB | bias [Cout] fp32
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef Tile256State<KS, SHIFT, DUAL> State;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int ntiles = p.ntm * p.ntn, nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+  const int my = (ntiles - bid + nwg - 1) / nwg;          // tiles of this workgroup (>= 1: the grid never exceeds the tiles)
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int HoWo = p.Ho * p.Wo;
+  const int frame_bytes = p.Hi * p.Wi * p.C * 2;
+  const int frame_bytes2 = DUAL ? p.Hi2 * p.Wi2 * p.C2 * 2 : 0;
+  const int nt1 = DUAL ? p.K1 / 64 : 0;                   // K-tiles of the first source
+  const int nt = p.Kp / 64;                               // K-tiles per tile (>= 2)
+  const int chunk = (lane & 3) ^ ((lane >> 4) & 3);       // global 16-B chunk held by this lane's LDS slot (source-side swizzle)
+
+  float *bias_lds = reinterpret_cast<float *>(lds + 131072);
+  for (int i = tid; i < p.Cout; i += 512) bias_lds[i] = p.bias[i];
+
+  // the loader state of the s-th tile of this workgroup (virtual block bid + s * nwg in conv_bf16_256's XCD-chunked order)
+  auto setup = [&](State &T, int s) {
+    const int v = bid + s * nwg, xcd = v & 7;
+    int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
+    if (tile >= ntiles) tile = ntiles - 1;                // (s == my: never staged live, kept in range for the arithmetic)
+    if (p.reverse) tile = ntiles - 1 - tile;
+    const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+    T.m0 = tm * 256;
+    T.n0 = tn * 256;
+    const int n_first = T.m0 / HoWo;
+    const int frame0 = SHIFT ? (n_first > 0 ? n_first - 1 : 0) : n_first;
+    const size_t a_bytes = ((size_t)p.N - frame0) * (size_t)frame_bytes;
+    T.pa = reinterpret_cast<const char *>(p.x) + (size_t)frame0 * frame_bytes;
+    T.sza = (int)(a_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : a_bytes);
+    T.pb = reinterpret_cast<const char *>(p.w) + (size_t)T.n0 * p.Kp * 2;
+    const size_t a2_bytes = DUAL ? ((size_t)p.N - n_first) * (size_t)frame_bytes2 : 0;
+    T.pa2 = reinterpret_cast<const char *>(DUAL ? p.x2 : p.x) + (size_t)n_first * frame_bytes2;
+    T.sza2 = (int)(a2_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : a2_bytes);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = (2 * wave + q) * 16 + (lane >> 2);
+      const int m = T.m0 + row;
+      const bool ok = m < p.M;
+      const int mm = ok ? m : T.m0;
+      const int n = mm / HoWo, rem = mm - n * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      const int base = (n - frame0) * frame_bytes + (iy0 * p.Wi + ix0) * p.C * 2 + chunk * 16;
+      T.a_off[q] = (KS == 1 && !ok) ? kInvalid : (unsigned)base;
+      if (KS == 3) {
+        unsigned mask = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            if ((unsigned)(iy0 + ky) < (unsigned)p.Hi && (unsigned)(ix0 + kx) < (unsigned)p.Wi) mask |= 1u << (ky * 3 + kx);
+        T.a_mask[q] = ok ? mask : 0u;
+      }
+      if (SHIFT) {
+        const int t = n % p.T;
+        T.a_offp[q] = (ok && t < p.T - 1) ? (unsigned)(base + frame_bytes) : kInvalid;
+        T.a_offm[q] = (ok && t > 0) ? (unsigned)(base - frame_bytes) : kInvalid;
+      }
+      if (DUAL)
+        T.a_off2[q] = ok ? (unsigned)((n - n_first) * frame_bytes2 + (oy * p.stride2 * p.Wi2 + ox * p.stride2) * p.C2 * 2 + chunk * 16)
+                         : kInvalid;
+      T.b_off[q] = (unsigned)(row * p.Kp * 2 + chunk * 16);
+    }
+  };
+
+  // Stage one half-operand of K-tile kt of the tile with state T into buffer `par`: which = 0 A k0-31, 1 B k0-31,
+  // 2 A k32-63, 3 B k32-63 (two 1-KiB pieces per wave); dead = kInvalid: zeros, no memory traffic
+  auto stage_of = [&](const State &T, int kt, unsigned par, int which, unsigned dead) {
+    const int kh = which >> 1;
+    const unsigned kbytes = (unsigned)kt * 128u + (unsigned)kh * 64u;
+    unsigned char *dst = lds + par * 65536u + ((which & 1) * 2 + kh) * 16384 + wave * 2048;
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(T.pa), 0, T.sza, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(T.pb), 0, 256 * p.Kp * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(T.pa2), 0, T.sza2, 0x00020000);
+    if (which & 1) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)(dst + q * 1024), 16, (int)(T.b_off[q] | dead), (int)kbytes, 0, 0);
+    } else if (KS == 1) {
+      unsigned mp = 0u, mm_ = 0u, m0_ = ~0u;
+      if (SHIFT) {
+        const int c = kt * 64 + kh * 32 + chunk * 8;      // first channel of this lane's chunk
+        mp = 0u - (unsigned)(c < p.fold);
+        mm_ = (0u - (unsigned)(c < 2 * p.fold)) & ~mp;
+        m0_ = ~(mp | mm_);
+      }
+      const bool second = DUAL && kt >= nt1;               // wave-uniform: which source this K-tile comes from
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        unsigned off = T.a_off[q];
+        if (SHIFT) off = (T.a_offp[q] & mp) | (T.a_offm[q] & mm_) | (T.a_off[q] & m0_);
+        if (DUAL && second)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, (lds_void *)(dst + q * 1024), 16, (int)(T.a_off2[q] | dead),
+                                                   (int)(kbytes - (unsigned)nt1 * 128u), 0, 0);
+        else
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(dst + q * 1024), 16, (int)(off | dead), (int)kbytes, 0, 0);
+      }
+    } else {
+      const int tap = (kt * 64) >> (p.logC4 + 2);         // C >= 64: a K-tile never straddles a tap
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const unsigned tap_off = (unsigned)(((ky * p.Wi + kx) * p.C + (kt * 64 - tap * p.C) + kh * 32) * 2);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(dst + q * 1024), 16,
+                                                 (int)((((T.a_mask[q] >> tap) & 1u) ? T.a_off[q] + tap_off : kInvalid) | dead), 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[4][2];      // acc[i][j]: rows = channels n0 + 64 wn + 32 j + .., columns = pixels m0 + 128 wm + 32 i + l31
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int sw = (l31 >> 2) & 3;
+  const unsigned a_rd0 = (unsigned)((wm * 128 + l31) * 64 + ((0 + half) ^ sw) * 16);
+  const unsigned a_rd1 = (unsigned)((wm * 128 + l31) * 64 + ((2 + half) ^ sw) * 16);
+  const unsigned b_rd0 = (unsigned)(32768 + (wn * 64 + l31) * 64 + ((0 + half) ^ sw) * 16);
+  const unsigned b_rd1 = (unsigned)(32768 + (wn * 64 + l31) * 64 + ((2 + half) ^ sw) * 16);
+  const float floor_ = p.relu ? 0.f : -INFINITY;
+
+  State cur, nxt;
+  setup(cur, 0);
+  // prologue: the six half-operands the schedule has in flight before the first K-tile starts (nt >= 2: all of tile 0)
+  stage_of(cur, 0, 0u, 0, 0u); stage_of(cur, 0, 0u, 1, 0u); stage_of(cur, 0, 0u, 2, 0u); stage_of(cur, 0, 0u, 3, 0u);
+  stage_of(cur, 1, 1u, 0, 0u); stage_of(cur, 1, 1u, 1, 0u);
+  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // K-tile 0, k 0-31 of A and B have landed (this wave's share); the bias is written
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();              // the stagger of conv_bf16_256: waves 4-7 one barrier behind
+
+  int g = 0;                                              // K-tiles done so far: the LDS buffer of a K-tile is its parity
+  for (int s = 0; s < my; ++s) {
+    const unsigned next_dead = s + 1 < my ? 0u : kInvalid;
+    setup(nxt, s + 1);
+    for (int kt = 0; kt < nt; ++kt, ++g) {
+      const unsigned buf = (unsigned)(g & 1) * 65536u;
+      // K-tile kt + d of the flat sequence: this tile's, or the first ones of the next tile
+      auto stage = [&](int d, int which) {
+        const unsigned par = (unsigned)((g + d) & 1);
+        if (kt + d < nt) stage_of(cur, kt + d, par, which, 0u);
+        else stage_of(nxt, kt + d - nt, par, which, next_dead);
+      };
+      const bool after_epilogue = kt == 0 && s > 0;       // 16 stores sit between the operands awaited here and the younger DMA
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        u32x4 af[4], bf[2];
+        {
+          const unsigned ra = buf + (ph >> 1) * 16384u + ((ph & 1) ? a_rd1 : a_rd0);
+          const unsigned rb = buf + (ph >> 1) * 16384u + ((ph & 1) ? b_rd1 : b_rd0);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const u32x4 *>(lds + rb + j * 2048);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4 *>(lds + ra + i * 2048);
+        }
+        if (ph == 0) stage(1, 2);
+        else if (ph == 1) stage(1, 3);
+        else if (ph == 2) stage(2, 0);
+        else stage(2, 1);
+        if (ph & 1) {
+          if (after_epilogue) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[j]), __builtin_bit_cast(bf16x8, af[i]),
+                                                                acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    // ---- epilogue of tile s, from registers (no LDS, no barrier): the next tile's first operands are in flight ----
+    {
+      const size_t y_bytes = ((size_t)p.M - cur.m0) * p.Cout * 2;
+      const int ysz = (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes);
+      const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<char *>(p.y) + (size_t)cur.m0 * p.Cout * 2, 0, ysz, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(reinterpret_cast<const char *>(RES ? p.res : p.y) + (size_t)cur.m0 * p.Cout * 2), 0, ysz, 0x00020000);
+      const int cbase = (cur.n0 + wn * 64) * 2 + half * 32;               // this lane's first byte within a pixel's row
+      u32x4 rres[2][RES ? 4 : 1];
+      auto load_res = [&](int i, int set) {
+        if constexpr (RES) {
+          const int o = (wm * 128 + i * 32 + l31) * p.Cout * 2 + cbase;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) rres[set][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, o, (k >> 1) * 64 + (k & 1) * 16, 0);
+        }
+      };
+      load_res(0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i + 1 < 4) load_res(i + 1, (i + 1) & 1);
+        const int o = (wm * 128 + i * 32 + l31) * p.Cout * 2 + cbase;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned pk[4][2];
+          unsigned rp[4][2];
+          if constexpr (RES) {   // the residual's 16-byte groups -> accumulator layout: the store swap backwards
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+              for (int w2 = 0; w2 < 2; ++w2) {
+                const auto sw2 = __builtin_amdgcn_permlane32_swap(rres[i & 1][2 * j + qq][w2], rres[i & 1][2 * j + qq][2 + w2], false, false);
+                rp[qq][w2] = sw2[0];
+                rp[qq + 2][w2] = sw2[1];
+              }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_lds + cur.n0 + wn * 64 + j * 32 + 8 * q + 4 * half);
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) {
+              float v0 = acc[i][j][4 * q + 2 * w2] + b[2 * w2], v1 = acc[i][j][4 * q + 2 * w2 + 1] + b[2 * w2 + 1];
+              if constexpr (RES) {
+                const unsigned rw = rp[q][w2];
+                v0 += __builtin_bit_cast(float, rw << 16);
+                v1 += __builtin_bit_cast(float, rw & 0xFFFF0000u);
+              }
+              pk[q][w2] = pack_bf16(fmaxf(v0, floor_), fmaxf(v1, floor_));
+            }
+          }
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) {
+              const auto r2 = __builtin_amdgcn_permlane32_swap(pk[qq][w2], pk[qq + 2][w2], false, false);
+              pk[qq][w2] = r2[0];
+              pk[qq + 2][w2] = r2[1];
+            }
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) {
+            const u32x4 ov = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rsrcY, o, j * 64 + qq * 16, 0);
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        }
+      }
+    }
+    cur = nxt;
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();              // the early group waits for the delayed one
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the dead tail stages (zeros) land before the workgroup leaves its LDS
+}
+
+bool conv_bf16_256p_valid(const ConvParams &p, int ks) {
+  return conv_bf16_256_valid(p, ks) && p.Kp >= 128 && p.Cout <= 2048;
+}
+
 // Per DEVICE, once: the CU count that sizes the persistent grids and the > 64 KB dynamic-LDS opt-in of every kernel
 // that needs one.  tsm_hip.h lets engines on several devices live in one process, so neither may be cached from
 // whichever device happened to launch first (defined below the last kernel it names).
@@ -1189,6 +1503,23 @@ static hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s) {
   else if (p.res) hipLaunchKernelGGL((conv_bf16_256_kernel<1, false, true, false>), grid, block, kLdsBytes, s, p);
   else if (p.x2) hipLaunchKernelGGL((conv_bf16_256_kernel<1, false, false, true>), grid, block, kLdsBytes, s, p);
   else hipLaunchKernelGGL((conv_bf16_256_kernel<1, false>), grid, block, kLdsBytes, s, p);
+  return hipGetLastError();
+}
+
+static hipError_t launch_conv_bf16_256p(ConvParams p, int ks, hipStream_t s) {
+  if (!conv_bf16_256p_valid(p, ks)) return hipErrorInvalidValue;
+  p.ntm = (p.M + 255) / 256;
+  p.ntn = p.Cout / 256;
+  const DeviceInfo &di = device_info();   // CU count of this device + the > 64 KB dynamic-LDS opt-in
+  if (di.status != hipSuccess) return di.status;
+  const int ntiles = p.ntm * p.ntn;
+  const int slots = di.n_cu & ~7;          // a multiple of 8: a workgroup's tiles then all sit in its own XCD's chunk
+  const dim3 grid((unsigned)(ntiles < slots || slots < 8 ? ntiles : slots)), block(512);
+  if (ks == 3) hipLaunchKernelGGL((conv_bf16_256p_kernel<3, false>), grid, block, kLds256pBytes, s, p);
+  else if (p.T > 0) hipLaunchKernelGGL((conv_bf16_256p_kernel<1, true>), grid, block, kLds256pBytes, s, p);
+  else if (p.res) hipLaunchKernelGGL((conv_bf16_256p_kernel<1, false, true, false>), grid, block, kLds256pBytes, s, p);
+  else if (p.x2) hipLaunchKernelGGL((conv_bf16_256p_kernel<1, false, false, true>), grid, block, kLds256pBytes, s, p);
+  else hipLaunchKernelGGL((conv_bf16_256p_kernel<1, false>), grid, block, kLds256pBytes, s, p);
   return hipGetLastError();
 }
 
@@ -2608,6 +2939,11 @@ static const DeviceInfo &device_info() {
   opt_in(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, true>), kLds256Bytes);
   opt_in(reinterpret_cast<const void *>(&conv_bf16_256_kernel<3, false>), kLds256Bytes);
   opt_in(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false, true, false>), kLds256Bytes);
+  opt_in(reinterpret_cast<const void *>(&conv_bf16_256p_kernel<1, false>), kLds256pBytes);
+  opt_in(reinterpret_cast<const void *>(&conv_bf16_256p_kernel<1, true>), kLds256pBytes);
+  opt_in(reinterpret_cast<const void *>(&conv_bf16_256p_kernel<3, false>), kLds256pBytes);
+  opt_in(reinterpret_cast<const void *>(&conv_bf16_256p_kernel<1, false, true, false>), kLds256pBytes);
+  opt_in(reinterpret_cast<const void *>(&conv_bf16_256p_kernel<1, false, false, true>), kLds256pBytes);
   opt_in(reinterpret_cast<const void *>(&conv_bf16_256_kernel<1, false, false, true>), kLds256Bytes);
   opt_in(reinterpret_cast<const void *>(&conv3x3_ws_kernel<false>), kWsLdsBytes);
   opt_in(reinterpret_cast<const void *>(&conv3x3_ws_kernel<true>), kWsLdsBytes3All);

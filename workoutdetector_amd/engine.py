@@ -225,7 +225,8 @@ class TsmEngine:
                 names += ([p + '.downsample'] if b == 0 else []) + [p + '.conv1', p + '.conv2', p + '.conv3']
         return names + ['head']
 
-    TILE_NAMES = {0: 'heuristic', 1: '128x128', 2: '128x64', 3: '64x64', 4: '32x32', 5: '128x128w8', 6: '256x256', 7: 'ws'}
+    TILE_NAMES = {0: 'heuristic', 1: '128x128', 2: '128x64', 3: '64x64', 4: '32x32', 5: '128x128w8', 6: '256x256', 7: 'ws',
+                  8: '256x256p'}
 
     @classmethod
     def tile_name(cls, code: int) -> str:
