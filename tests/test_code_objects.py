@@ -67,6 +67,19 @@ def test_bf16_256_tile_fits_one_eight_wave_workgroup(md):
         assert codeobj.workgroups_per_cu(r, 131072) == 1
 
 
+def test_persistent_bf16_256_tile_budget(md):
+    """conv_bf16_256p_kernel: the same 8-wave workgroup (<= 256 registers per wave at 2 waves per SIMD) with the
+    accumulators, two tiles' loader state and -- residual arm -- two slabs of prefetched residual live together; NO scratch
+    (its counted vmcnt waits assume exactly the vector-memory operations the source issues); 128 KB + the bias of up to
+    2048 channels of dynamic LDS = one workgroup per CU."""
+    for args in ('1, false, false, false', '1, true, false, false', '3, false, false, false', '1, false, true, false',
+                 '1, false, false, true'):
+        r = _one(md, f'conv_bf16_256p_kernel<{args}>')
+        assert r['.max_flat_workgroup_size'] == 512 and r['.vgpr_count'] <= 256 and r['.group_segment_fixed_size'] == 0
+        assert r['.private_segment_fixed_size'] == 0 and r['.vgpr_spill_count'] == 0
+        assert codeobj.workgroups_per_cu(r, 131072 + 8192) == 1
+
+
 def test_weight_stationary_kernels_own_a_whole_register_file(md):
     """One wave per SIMD, up to 512 unified registers each (weights pinned in the accumulation half), no scratch; the
     dynamic LDS they are launched with (csrc constants, static_assert'ed <= 160 KiB at compile time) leaves exactly one

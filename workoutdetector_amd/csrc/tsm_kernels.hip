@@ -1345,6 +1345,23 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
   const unsigned b_rd1 = (unsigned)(32768 + (wn * 64 + l31) * 64 + ((2 + half) ^ sw) * 16);
   const float floor_ = p.relu ? 0.f : -INFINITY;
 
+  // residual (RES): this lane's 16-byte groups of a 32-pixel slab, 4 per slab in two register sets.  Slabs 0 and 1 are
+  // requested at the START of a tile's last K-tile -- older than that K-tile's four operand stages, so that consuming
+  // them in the epilogue does not wait for the next tile's operands (vector-memory operations retire in order) --
+  // slabs 2 and 3 inside the epilogue, each once its register set is free.
+  u32x4 rres[2][RES ? 4 : 1];
+  auto load_res = [&](const State &T, int i, int set) {
+    if constexpr (RES) {
+      const size_t y_bytes = ((size_t)p.M - T.m0) * p.Cout * 2;
+      const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char *>(reinterpret_cast<const char *>(p.res) + (size_t)T.m0 * p.Cout * 2), 0,
+          (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
+      const int o = (wm * 128 + i * 32 + l31) * p.Cout * 2 + (T.n0 + wn * 64) * 2 + half * 32;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rres[set][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, o, (k >> 1) * 64 + (k & 1) * 16, 0);
+    }
+  };
+
   State cur, nxt;
   setup(cur, 0);
   // prologue: the six half-operands the schedule has in flight before the first K-tile starts (nt >= 2: all of tile 0)
@@ -1367,6 +1384,11 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
         else stage_of(nxt, kt + d - nt, par, which, next_dead);
       };
       const bool after_epilogue = kt == 0 && s > 0;       // 16 stores sit between the operands awaited here and the younger DMA
+      const bool with_res = RES && kt == nt - 1;          // 8 residual loads sit there (issued right here)
+      if (with_res) {
+        load_res(cur, 0, 0);
+        load_res(cur, 1, 1);
+      }
 #pragma unroll
       for (int ph = 0; ph < 4; ++ph) {
         u32x4 af[4], bf[2];
@@ -1384,6 +1406,7 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
         else stage(2, 1);
         if (ph & 1) {
           if (after_epilogue) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+          else if (with_res) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1408,21 +1431,9 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
       const int ysz = (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes);
       const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<char *>(p.y) + (size_t)cur.m0 * p.Cout * 2, 0, ysz, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char *>(reinterpret_cast<const char *>(RES ? p.res : p.y) + (size_t)cur.m0 * p.Cout * 2), 0, ysz, 0x00020000);
       const int cbase = (cur.n0 + wn * 64) * 2 + half * 32;               // this lane's first byte within a pixel's row
-      u32x4 rres[2][RES ? 4 : 1];
-      auto load_res = [&](int i, int set) {
-        if constexpr (RES) {
-          const int o = (wm * 128 + i * 32 + l31) * p.Cout * 2 + cbase;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) rres[set][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, o, (k >> 1) * 64 + (k & 1) * 16, 0);
-        }
-      };
-      load_res(0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (i + 1 < 4) load_res(i + 1, (i + 1) & 1);
         const int o = (wm * 128 + i * 32 + l31) * p.Cout * 2 + cbase;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1468,6 +1479,7 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         }
+        if (i + 2 < 4) load_res(cur, i + 2, i & 1);
       }
     }
     cur = nxt;
