@@ -277,7 +277,7 @@ def test_bench_names_the_kernels_rocprof_prints():
         text = open(os.path.join(root, 'profiles', f'r03_{mode}_kernel_stats.csv')).read()
         seen[mode] = text
     cases = [('f32', '64x64', 'f32', 256), ('f32', '64x64+conv3', 'f32', 128), ('f32', '64x64+conv3', 'f32', 64),
-             ('bf16c5', '256x256', 'bf16', 256), ('bf16c5', 'ws', 'bf16', 128), ('bf16x3', '128x128w8', 'bf16x3', 256),
+             ('bf16c5', '256x256', 'bf16', 256), ('bf16c5', '256x256p', 'bf16', 256), ('bf16c5', 'ws', 'bf16', 128), ('bf16x3', '128x128w8', 'bf16x3', 256),
              ('bf16x3', '128x128+conv3', 'bf16x3', 128)]
     for mode, tile, dtype, cmid in cases:
         name, with_conv3 = bench.kernel_of(tile, dtype, cmid)

@@ -39,13 +39,13 @@ def main(path, frames=256, size=224):
     # Expected launch order, consumed against the trace: the stem; per block [downsample,] conv1, then either conv2 and
     # conv3 (the latter fused with the downsample branch in a stage's first block) or ONE conv23_fused /
     # conv3x3_ws_kernel<true> launch.
-    def _dual(name):      # conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, PREC, DUAL, SEG> / conv_bf16_256_kernel<KS, SHIFT, RES, DUAL>
+    def _dual(name):      # conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, PREC, DUAL, SEG> / conv_bf16_256[p]_kernel<KS, SHIFT, RES, DUAL>
         if '<' not in name:
             return False
         args = [a.strip() for a in name.split('<')[1].split('>')[0].split(',')]
         if 'conv_igemm<' in name:
             return len(args) > 8 and args[8] == 'true'
-        return 'conv_bf16_256_kernel<' in name and len(args) > 3 and args[3] == 'true'
+        return ('conv_bf16_256_kernel<' in name or 'conv_bf16_256p_kernel<' in name) and len(args) > 3 and args[3] == 'true'
     n_down = sum(_dual(r['Kernel_Name']) for r in convs)
     rows, it = [], iter(convs)
 

@@ -20,7 +20,7 @@ echo "== f32 headline"; run_stats f32 256 224
 DOMINANT="conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, true>" UPDATE="32 8 224 224" bash tools/pmc_traffic.sh ${tag}_f32 > $O/${tag}_f32_hbm_traffic.txt 2>&1; tail -3 $O/${tag}_f32_hbm_traffic.txt
 bash tools/pmc_sq.sh ${tag}_f32; cp $O/pmc_sq_${tag}_f32.txt $O/${tag}_f32_pmc_sq.txt
 echo "== bf16 config 5"; run_stats bf16c5 1024 256 --config 5
-DOMINANT="conv_bf16_256_kernel<3, false, false, false>" UPDATE="64 16 256 256" bash tools/pmc_traffic.sh ${tag}_bf16c5 --config 5 > $O/${tag}_bf16c5_hbm_traffic.txt 2>&1; tail -3 $O/${tag}_bf16c5_hbm_traffic.txt
+DOMINANT="conv_bf16_256p_kernel<3, false, false, false>" UPDATE="64 16 256 256" bash tools/pmc_traffic.sh ${tag}_bf16c5 --config 5 > $O/${tag}_bf16c5_hbm_traffic.txt 2>&1; tail -3 $O/${tag}_bf16c5_hbm_traffic.txt
 bash tools/pmc_sq.sh ${tag}_bf16c5 --config 5; cp $O/pmc_sq_${tag}_bf16c5.txt $O/${tag}_bf16c5_pmc_sq1.txt
 PMC="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
   bash tools/pmc_sq.sh ${tag}_bf16c5b --config 5; cp $O/pmc_sq_${tag}_bf16c5b.txt $O/${tag}_bf16c5_pmc_sq2.txt
