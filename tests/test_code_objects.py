@@ -77,7 +77,7 @@ def test_persistent_bf16_256_tile_budget(md):
         r = _one(md, f'conv_bf16_256p_kernel<{args}>')
         assert r['.max_flat_workgroup_size'] == 512 and r['.vgpr_count'] <= 256 and r['.group_segment_fixed_size'] == 0
         assert r['.private_segment_fixed_size'] == 0 and r['.vgpr_spill_count'] == 0
-        assert codeobj.workgroups_per_cu(r, 131072 + 8192) == 1
+        assert codeobj.workgroups_per_cu(r, 131072 + 8192 + 8 * 2176) == 1
 
 
 def test_weight_stationary_kernels_own_a_whole_register_file(md):

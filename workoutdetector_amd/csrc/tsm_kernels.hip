@@ -1197,7 +1197,7 @@ bool conv_bf16_256_valid(const ConvParams &p, int ks) {
 // Needs at least two K-tiles per tile (K >= 128: "kt + 2" must not skip a tile) and Cout <= 2048 (the bias in LDS).
 // Bit-identical to conv_bf16_256 and to conv_igemm's bf16 tiles; the tuner picks per layer.
 // ---------------------------------------------------------------------------------------------
-constexpr size_t kLds256pBytes = 131072 + 8192;
+constexpr size_t kLds256pBytes = 131072 + 8192 + 8 * 2176;   // two operand buffers | bias [<= 2048] fp32 | residual arm: eight [8][68] fp32 sub-slabs
 
 template <int KS, bool SHIFT, bool DUAL> struct Tile256State {
   unsigned a_off[2], b_off[2];
@@ -1345,20 +1345,25 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
   const unsigned b_rd1 = (unsigned)(32768 + (wn * 64 + l31) * 64 + ((2 + half) ^ sw) * 16);
   const float floor_ = p.relu ? 0.f : -INFINITY;
 
-  // residual (RES): this lane's 16-byte groups of a 32-pixel slab, 4 per slab in two register sets.  Slabs 0 and 1 are
-  // requested at the START of a tile's last K-tile -- older than that K-tile's four operand stages, so that consuming
-  // them in the epilogue does not wait for the next tile's operands (vector-memory operations retire in order) --
-  // slabs 2 and 3 inside the epilogue, each once its register set is free.
-  u32x4 rres[2][RES ? 4 : 1];
-  auto load_res = [&](const State &T, int i, int set) {
+  // Residual arm (RES): the product is NOT transposed and the epilogue goes through LDS like conv_bf16_256's -- whole
+  // 128-byte row segments of the residual and of the output per 8 lanes; the transposed register epilogue would fetch the
+  // residual as 16 bytes per lane, two lanes per pixel, and lost to conv_bf16_256 on exactly these launches -- but in
+  // SUB-SLABS of 8 rows x 64 channels ([8][68] fp32 per wave = 17 KB for the workgroup, behind the bias): the two operand
+  // buffers stay untouched, so the next tile's operands still land under the epilogue.  A wave tile is 16 sub-slabs; the
+  // residual of sub-slab t is ONE 16-byte load per lane (row t * 8 + lane / 8, channels 8 (lane % 8) ..), eight of
+  // them in flight: sub-slabs 0-7 are requested at the START of the tile's last K-tile -- older than that K-tile's four
+  // operand stages, so that consuming them does not wait for the next tile's operands (vector-memory operations retire
+  // in order) -- and sub-slab t + 8 when sub-slab t has been consumed.
+  u32x4 rres[RES ? 8 : 1];
+  const int c8 = lane & 7, r8l = lane >> 3;
+  auto load_res = [&](const State &T, int t, int slot) {
     if constexpr (RES) {
       const size_t y_bytes = ((size_t)p.M - T.m0) * p.Cout * 2;
       const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char *>(reinterpret_cast<const char *>(p.res) + (size_t)T.m0 * p.Cout * 2), 0,
           (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
-      const int o = (wm * 128 + i * 32 + l31) * p.Cout * 2 + (T.n0 + wn * 64) * 2 + half * 32;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) rres[set][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, o, (k >> 1) * 64 + (k & 1) * 16, 0);
+      rres[slot] = __builtin_amdgcn_raw_buffer_load_b128(
+          rsrcR, ((wm * 128 + t * 8 + r8l) * p.Cout + T.n0 + wn * 64 + c8 * 8) * 2, 0, 0);
     }
   };
 
@@ -1386,8 +1391,8 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
       const bool after_epilogue = kt == 0 && s > 0;       // 16 stores sit between the operands awaited here and the younger DMA
       const bool with_res = RES && kt == nt - 1;          // 8 residual loads sit there (issued right here)
       if (with_res) {
-        load_res(cur, 0, 0);
-        load_res(cur, 1, 1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) load_res(cur, t, t);
       }
 #pragma unroll
       for (int ph = 0; ph < 4; ++ph) {
@@ -1418,15 +1423,17 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[j]), __builtin_bit_cast(bf16x8, af[i]),
-                                                                acc[i][j], 0, 0, 0);
+            acc[i][j] = RES ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]),
+                                                                      acc[i][j], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[j]), __builtin_bit_cast(bf16x8, af[i]),
+                                                                      acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
       }
     }
-    // ---- epilogue of tile s, from registers (no LDS, no barrier): the next tile's first operands are in flight ----
-    {
+    // ---- epilogue of tile s: the next tile's first operands are in flight ----
+    if constexpr (!RES) {   // from registers (no LDS, no barrier)
       const size_t y_bytes = ((size_t)p.M - cur.m0) * p.Cout * 2;
       const int ysz = (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes);
       const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
@@ -1438,28 +1445,12 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           unsigned pk[4][2];
-          unsigned rp[4][2];
-          if constexpr (RES) {   // the residual's 16-byte groups -> accumulator layout: the store swap backwards
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-              for (int w2 = 0; w2 < 2; ++w2) {
-                const auto sw2 = __builtin_amdgcn_permlane32_swap(rres[i & 1][2 * j + qq][w2], rres[i & 1][2 * j + qq][2 + w2], false, false);
-                rp[qq][w2] = sw2[0];
-                rp[qq + 2][w2] = sw2[1];
-              }
-          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 b = *reinterpret_cast<const f32x4 *>(bias_lds + cur.n0 + wn * 64 + j * 32 + 8 * q + 4 * half);
 #pragma unroll
             for (int w2 = 0; w2 < 2; ++w2) {
               float v0 = acc[i][j][4 * q + 2 * w2] + b[2 * w2], v1 = acc[i][j][4 * q + 2 * w2 + 1] + b[2 * w2 + 1];
-              if constexpr (RES) {
-                const unsigned rw = rp[q][w2];
-                v0 += __builtin_bit_cast(float, rw << 16);
-                v1 += __builtin_bit_cast(float, rw & 0xFFFF0000u);
-              }
               pk[q][w2] = pack_bf16(fmaxf(v0, floor_), fmaxf(v1, floor_));
             }
           }
@@ -1479,8 +1470,41 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         }
-        if (i + 2 < 4) load_res(cur, i + 2, i & 1);
       }
+    } else {                // residual arm: 16 sub-slabs of 8 rows through this wave's [8][68] fp32 slab
+      float *Cs = reinterpret_cast<float *>(lds + 131072 + 8192 + wave * 2176);
+      const size_t y_bytes = ((size_t)p.M - cur.m0) * p.Cout * 2;
+      const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<char *>(p.y) + (size_t)cur.m0 * p.Cout * 2, 0, (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
+      const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(bias_lds + cur.n0 + wn * 64 + c8 * 8);
+      const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(bias_lds + cur.n0 + wn * 64 + c8 * 8 + 4);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = t >> 2, q = t & 3;          // rows 32 i + 8 q .. + 8 of the wave tile: accumulator elements 4 q .. 4 q + 3
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cs[(4 * half + r) * 68 + j * 32 + l31] = acc[i][j][4 * q + r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (same wave wrote it: no barrier needed)
+        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8);
+        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8 + 4);
+        float v[8] = {c0[0] + bias0[0], c0[1] + bias0[1], c0[2] + bias0[2], c0[3] + bias0[3],
+                      c1[0] + bias1[0], c1[1] + bias1[1], c1[2] + bias1[2], c1[3] + bias1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += split_elem(rres[t & 7], e);
+        u32x4 o;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) o[w2] = pack_bf16(fmaxf(v[2 * w2], floor_), fmaxf(v[2 * w2 + 1], floor_));
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, ((wm * 128 + t * 8 + r8l) * p.Cout + cur.n0 + wn * 64 + c8 * 8) * 2, 0, 0);
+        if (t + 8 < 16) load_res(cur, t + 8, t & 7);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slab reads done before the next sub-slab overwrites it
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     }
     cur = nxt;
   }
