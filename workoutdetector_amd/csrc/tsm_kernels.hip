@@ -1186,14 +1186,19 @@ bool conv_bf16_256_valid(const ConvParams &p, int ks) {
 //     descriptors, current / next); the four-half-operands-in-flight schedule, its counted waits, the staggered wave
 //     groups and the barriers are conv_bf16_256's, unchanged, and run from the first K-tile of the first tile to the
 //     last K-tile of the last;
-//   * the epilogue touches no LDS, so it can sit between two K-tiles while the next tile's operands land: the product
-//     is TRANSPOSED (A = weights, B = pixels: the fragment formats are symmetric, the products of an output enter its
-//     accumulator in the same k order -> same bits), a lane then holds 4-channel runs of ONE pixel, and bias +
-//     residual + ReLU + bf16 + v_permlane32_swap give 16-byte stores straight from registers (conv3x3_ws's epilogue);
+//   * the epilogue leaves the two operand buffers alone, so it can sit between two K-tiles while the next tile's operands
+//     land.  Without a residual it touches no LDS at all: the product is TRANSPOSED (A = weights, B = pixels: the fragment
+//     formats are symmetric, the products of an output enter its accumulator in the same k order -> same bits), a lane
+//     then holds 4-channel runs of ONE pixel, and bias + ReLU + bf16 + v_permlane32_swap give 16-byte stores straight
+//     from registers (conv3x3_ws's epilogue; measured against the slab form below: 3-6 % faster on these arms).  With a
+//     residual the product is not transposed and the epilogue goes through eight wave-private [8][68] fp32 SUB-SLABS
+//     behind the bias (whole 128-byte row segments of residual and output per 8 lanes; the register form, 16 bytes per
+//     lane and two lanes per pixel, lost to conv_bf16_256 on exactly these launches), residual eight sub-slabs ahead;
 //     the bias of all Cout channels sits in LDS behind the two buffers;
 //   * the 16 stores of an epilogue are younger than the operands the next K-tile waits for: its two counted waits
 //     are vmcnt(8 + 16) instead of vmcnt(8) (vector-memory operations retire in order; a vmcnt(8) there would wait
-//     for the stores' completion).
+//     for the stores' completion); the residual arm requests sub-slabs 0-7 at the START of the tile's last K-tile,
+//     whose waits are therefore vmcnt(8 + 8).
 // Needs at least two K-tiles per tile (K >= 128: "kt + 2" must not skip a tile) and Cout <= 2048 (the bias in LDS).
 // Bit-identical to conv_bf16_256 and to conv_igemm's bf16 tiles; the tuner picks per layer.
 // ---------------------------------------------------------------------------------------------
