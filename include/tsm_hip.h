@@ -149,7 +149,7 @@ int tsm_layer_times(tsm_engine *e, int32_t forward_index, float *ms_out, int32_t
 /* Conv tile code the engine's autotuner chose for each conv launch of an `n_clips` forward, in launch order (stem,
  * then per block [downsample,] conv1, conv2, conv3): 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x32 (one wave),
  * 5 = 128x128 on 8 waves, 6 = 256x256 LDS-DMA kernel (bf16), 7 = weight-stationary 3x3 (bf16, 64 -> 64 / 128 -> 128
- * channels), 0 = not tuned (heuristic); + 256 = split-K form of a segmented fp32 layer (one workgroup per tile and K
+ * channels), 8 = the 256x256 kernel run persistently over a workgroup's tiles (bf16, K >= 128), 0 = not tuned (heuristic); + 256 = split-K form of a segmented fp32 layer (one workgroup per tile and K
  * segment, combined in segment order); + 1024 (on conv2's code) = the block runs conv2 + conv3 + residual as ONE launch
  * (conv3's slot is then not used); + 2048 (on conv1's code) = the WHOLE block -- shift, conv1, conv2, conv3 (+ the fused
  * downsample branch) + identity -- runs as ONE launch (bf16 layer1; the conv2 / conv3 slots are then not used).
