@@ -103,6 +103,15 @@ def test_gather_clips_equals_the_reference_windows(hip_lib, layout_name):
         buf = torch.full((3 + (hi - lo) + 2, 8) + tuple(frames.shape[1:]), -7.0, device='cuda')
         engine.gather_clips(frames, f_lo, total, lo, hi - lo, out=buf[3:3 + hi - lo])
         assert torch.equal(buf[3:3 + hi - lo], want) and bool((buf[:3] == -7).all()) and bool((buf[3 + hi - lo:] == -7).all())
+    # a padded tail on 16-byte frames, and more rows than one launch cuts (65535: the binding splits the range) -- the
+    # windows stay those of index_select
+    for n_buf, n_clips in ((4200, 1050), (70000, 17000)):       # 8 400 rows with a padded last clip; 136 000 rows = three launches
+        buf = torch.arange(n_buf * 4, dtype=torch.float32, device='cuda').reshape(n_buf, 4)
+        total = 2 * (n_buf - 1)
+        got = engine.gather_clips(buf, 0, total, 0, n_clips)
+        src = 8 * torch.arange(n_clips)[:, None] + 2 * torch.arange(8)[None, :]
+        idx = torch.where(src < total, src // 2, torch.full_like(src, n_buf - 1))
+        assert torch.equal(got, buf[idx.cuda()]), (n_buf, n_clips)
     # refusals: nothing may be launched for a range that leaves the buffer
     frames = torch.zeros((6, 24, 24, 4), device='cuda')
     for kw in [dict(first_frame=0, total_frames=77, first_clip=0, n_clips=2),      # needs 12 even frames, 6 in the buffer
