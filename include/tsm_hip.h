@@ -33,7 +33,13 @@
  *   - An engine owns its weights and workspace on ONE device; it is NOT re-entrant: one
  *     in-flight call per engine.  Independent engines (other devices / processes) coexist.
  *   - Caller owns all input / output buffers.  With TSM_MEM_HOST the call copies and
- *     synchronises before returning; with TSM_MEM_DEVICE the call only enqueues on `stream`.
+ *     synchronises before returning; with TSM_MEM_DEVICE the call only enqueues on `stream` -- with ONE
+ *     exception: the FIRST tsm_forward of a new power-of-two bucket of n_clips tunes its kernels first (unless
+ *     TSM_AUTOTUNE=0, or TSM_TUNE_CACHE names a file that already holds this bucket): it times every candidate on the
+ *     real launches, which synchronises with `stream` about a hundred times and takes a few hundred ms, so that call is
+ *     neither asynchronous nor legal inside a stream capture.  Run one forward per bucket at start-up (TsmEngine.warmup
+ *     in the Python host) before capturing a graph or relying on enqueue-only behaviour; every later call of that
+ *     bucket allocates nothing, synchronises nothing and is capture-safe.
  *   - Activations inside the engine are NHWC fp32.
  */
 #ifndef TSM_HIP_H_
@@ -154,8 +160,10 @@ int tsm_layer_times(tsm_engine *e, int32_t forward_index, float *ms_out, int32_t
  * (conv3's slot is then not used); + 2048 (on conv1's code) = the WHOLE block -- shift, conv1, conv2, conv3 (+ the fused
  * downsample branch) + identity -- runs as ONE launch (bf16 layer1; the conv2 / conv3 slots are then not used).
  * The first tsm_forward with a new power-of-two bucket of n_clips
- * times every valid code per layer once (results are bit-identical across codes); TSM_AUTOTUNE=0 in the environment
- * at tsm_create disables it.  Every TSM_* environment variable is read once, in tsm_create. */
+ * times every valid code per layer once, SYNCHRONOUSLY (see Conventions: not capture-safe, a few hundred ms; results are
+ * bit-identical across codes); TSM_AUTOTUNE=0 in the environment at tsm_create disables it, TSM_TUNE_CACHE=<file> lets a
+ * later process (or the other ranks of a job) read the choices instead of timing again.  Every TSM_* environment
+ * variable is read once, in tsm_create. */
 int tsm_conv_tiles(tsm_engine *e, int32_t n_clips, int32_t *tiles_out, int32_t cap, int32_t *n_out);
 
 /* Per-op entry points (device pointers; used by the parity tests and as building blocks) ----- */
@@ -202,7 +210,10 @@ int tsm_preprocess(const void *frames, int32_t pixel, int32_t n, int32_t h, int3
  *   out[c][k] = source frame clip_step * (first_clip + c) + clip_stride * k   if that index < total_frames,
  *               buffer frame pad_frame                                         otherwise (the transformed zero frame).
  * Every index is validated on the host before the launch (TSM_ERR_INVALID_ARG, nothing launched): frame_bytes % 16 == 0,
- * clip_step % clip_stride == 0, each clip starts inside the video, all frames it reads lie in the buffer. */
+ * clip_step % clip_stride == 0, each clip starts inside the video, all frames it reads lie in the buffer, and -- when the
+ * range has a padded tail -- pad_frame lies in the buffer and is NOT one of the frames the range reads as video frames.
+ * n_clips is not limited by the launch geometry: ranges of more than 65535 (clip, segment) rows are cut into several
+ * launches inside the call. */
 int tsm_gather_clips(const void *frames, int64_t n_frames, int64_t frame_bytes, int64_t first_frame, int64_t total_frames,
                      int64_t pad_frame, int64_t first_clip, int32_t n_clips, int32_t n_segment, int32_t clip_step,
                      int32_t clip_stride, void *out, void *stream);

@@ -1,12 +1,26 @@
 /* The C ABI from plain C: include/tsm_hip.h must compile as C99 and libtsm_hip.so must be usable without
  * Python.  Built by tests/test_abi.py with gcc; executed only where a GPU exists (tests/test_engine_gpu.py).
  * Usage: abi_c_smoke            -> checks the no-GPU / bad-argument error paths only (exit 0)
- *        abi_c_smoke run       -> additionally creates an engine with all-zero weights and runs one clip */
+ *        abi_c_smoke run       -> additionally creates an engine with all-zero weights and runs one clip
+ *        abi_c_smoke pipeline W.bin V.bin OUT.bin
+ *                              -> the device pipeline of the dataset loop, from C: weights from W.bin, a uint8 video from
+ *                                 V.bin, tsm_preprocess -> tsm_gather_clips -> tsm_forward(TSM_LAYOUT_NTHWC4, device
+ *                                 memory) -> tsm_scores_to_states; logits + states + top scores are written to OUT.bin and
+ *                                 compared bit for bit with the Python binding's by tests/test_engine_gpu.py.
+ * File formats (little endian): W.bin = int32 n, then per tensor int32 name_len, name, int32 ndim, int64 shape[ndim],
+ * float32 data; V.bin = int32 frames, h, w, resize, crop, then uint8 [frames][h][w][3]; OUT.bin = int32 n_clips, float32
+ * logits [n_clips][12], int32 states [n_clips], float32 top [n_clips]. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "tsm_hip.h"
+
+/* the four HIP runtime calls a C host needs for device buffers (libamdhip64; declared by hand: this file stays plain C99) */
+extern int hipMalloc(void **ptr, size_t size);
+extern int hipFree(void *ptr);
+extern int hipMemcpy(void *dst, const void *src, size_t bytes, int kind); /* 1 = host to device, 2 = device to host */
+extern int hipDeviceSynchronize(void);
 
 static int fill_zero_weights(tsm_engine *e) {
   /* every tensor of TSM.state_dict(): zeros, BatchNorm variance ones -> logits must equal fc.bias */
@@ -60,6 +74,97 @@ static int fill_zero_weights(tsm_engine *e) {
   return 0;
 }
 
+static int read_exact(FILE *f, void *dst, size_t bytes) { return fread(dst, 1, bytes, f) == bytes ? 0 : -1; }
+
+static int load_weights(tsm_engine *e, const char *path) {
+  FILE *f = fopen(path, "rb");
+  int32_t n = 0;
+  if (!f || read_exact(f, &n, 4)) return -1;
+  for (int32_t i = 0; i < n; ++i) {
+    char name[256];
+    int32_t len = 0, ndim = 0;
+    int64_t shp[4] = {1, 1, 1, 1};
+    size_t cnt = 1;
+    float *buf;
+    int rc;
+    if (read_exact(f, &len, 4) || len <= 0 || len >= (int32_t)sizeof name || read_exact(f, name, (size_t)len)) return -2;
+    name[len] = 0;
+    if (read_exact(f, &ndim, 4) || ndim < 1 || ndim > 4 || read_exact(f, shp, 8 * (size_t)ndim)) return -3;
+    for (int d = 0; d < ndim; ++d) cnt *= (size_t)shp[d];
+    buf = (float *)malloc(cnt * sizeof(float));
+    if (!buf || read_exact(f, buf, cnt * sizeof(float))) return -4;
+    rc = tsm_set_tensor(e, name, buf, shp, ndim);
+    free(buf);
+    if (rc) { fprintf(stderr, "%s: %s\n", name, tsm_last_error(e)); return rc; }
+  }
+  fclose(f);
+  return 0;
+}
+
+/* tsm_preprocess -> tsm_gather_clips -> tsm_forward (device memory, packed layout) -> tsm_scores_to_states, all from C */
+static int pipeline(const char *wpath, const char *vpath, const char *opath) {
+  tsm_config cfg;
+  tsm_engine *e = NULL;
+  FILE *f = fopen(vpath, "rb");
+  int32_t hdr[5];
+  if (!f || read_exact(f, hdr, sizeof hdr)) { fprintf(stderr, "video header\n"); return 20; }
+  {
+    const int32_t frames = hdr[0], h = hdr[1], w = hdr[2], resize = hdr[3], crop = hdr[4];
+    const int32_t n_even = (frames + 1) / 2, n_clips = (frames + 7) / 8;
+    const size_t fbytes = (size_t)h * w * 3, packed = (size_t)crop * crop * 4 * sizeof(float);
+    unsigned char *video = (unsigned char *)malloc(fbytes * (size_t)frames);
+    unsigned char *even = (unsigned char *)calloc((size_t)n_even + 1, fbytes);   /* every 2nd frame + one zero frame (the padded tail) */
+    void *d_even = NULL, *d_frames = NULL, *d_clips = NULL, *d_logits = NULL, *d_states = NULL, *d_top = NULL;
+    float *logits = (float *)malloc((size_t)n_clips * 12 * sizeof(float)), *top = (float *)malloc((size_t)n_clips * sizeof(float));
+    int32_t *states = (int32_t *)malloc((size_t)n_clips * sizeof(int32_t));
+    FILE *o;
+    if (!video || !even || !logits || !top || !states || read_exact(f, video, fbytes * (size_t)frames)) return 21;
+    fclose(f);
+    for (int32_t j = 0; j < n_even; ++j) memcpy(even + (size_t)j * fbytes, video + (size_t)(2 * j) * fbytes, fbytes);
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = (int32_t)sizeof cfg; cfg.num_class = 12; cfg.num_segments = 8; cfg.height = crop; cfg.width = crop;
+    cfg.shift_div = 8; cfg.is_shift = 1; cfg.max_clips = n_clips; cfg.device_id = 0; cfg.dtype = TSM_DTYPE_F32;
+    if (tsm_create(&cfg, &e)) { fprintf(stderr, "create: %s\n", tsm_last_error(NULL)); return 22; }
+    if (load_weights(e, wpath)) { fprintf(stderr, "weights\n"); return 23; }
+    if (tsm_finalize(e)) { fprintf(stderr, "finalize: %s\n", tsm_last_error(e)); return 24; }
+    if (hipMalloc(&d_even, fbytes * ((size_t)n_even + 1)) || hipMalloc(&d_frames, packed * ((size_t)n_even + 1)) ||
+        hipMalloc(&d_clips, packed * 8 * (size_t)n_clips) || hipMalloc(&d_logits, (size_t)n_clips * 12 * sizeof(float)) ||
+        hipMalloc(&d_states, (size_t)n_clips * sizeof(int32_t)) || hipMalloc(&d_top, (size_t)n_clips * sizeof(float)))
+      return 25;
+    if (hipMemcpy(d_even, even, fbytes * ((size_t)n_even + 1), 1)) return 26;
+    /* the test transform without the / 255 (utils/inference_count.py:412-414), into the fp32 engine's packed layout */
+    if (tsm_preprocess(d_even, TSM_PIXEL_U8, n_even + 1, h, w, (float *)d_frames, TSM_LAYOUT_NTHWC4, resize, crop, 0, NULL)) {
+      fprintf(stderr, "preprocess: %s\n", tsm_last_error(NULL)); return 27;
+    }
+    /* vid[i:i + 16:2] for i in range(0, len(vid), 8): buffer frame j = source frame 2 j, the zero frame pads the tail */
+    if (tsm_gather_clips(d_frames, n_even + 1, (int64_t)packed, 0, frames, n_even, 0, n_clips, 8, 8, 2, d_clips, NULL)) {
+      fprintf(stderr, "gather: %s\n", tsm_last_error(NULL)); return 28;
+    }
+    if (tsm_forward(e, d_clips, TSM_MEM_DEVICE, TSM_LAYOUT_NTHWC4, n_clips, (float *)d_logits, NULL)) {
+      fprintf(stderr, "forward: %s\n", tsm_last_error(e)); return 29;
+    }
+    if (tsm_scores_to_states((const float *)d_logits, n_clips, 12, 1, 0.1f, (int32_t *)d_states, (float *)d_top, NULL)) {
+      fprintf(stderr, "states: %s\n", tsm_last_error(NULL)); return 30;
+    }
+    if (hipDeviceSynchronize()) return 31;
+    if (hipMemcpy(logits, d_logits, (size_t)n_clips * 12 * sizeof(float), 2) || hipMemcpy(states, d_states, (size_t)n_clips * sizeof(int32_t), 2) ||
+        hipMemcpy(top, d_top, (size_t)n_clips * sizeof(float), 2))
+      return 32;
+    o = fopen(opath, "wb");
+    if (!o) return 33;
+    fwrite(&n_clips, 4, 1, o);
+    fwrite(logits, sizeof(float), (size_t)n_clips * 12, o);
+    fwrite(states, sizeof(int32_t), (size_t)n_clips, o);
+    fwrite(top, sizeof(float), (size_t)n_clips, o);
+    fclose(o);
+    tsm_destroy(e);
+    hipFree(d_even); hipFree(d_frames); hipFree(d_clips); hipFree(d_logits); hipFree(d_states); hipFree(d_top);
+    free(video); free(even); free(logits); free(top); free(states);
+    printf("abi_c_smoke: pipeline ok, %d clips\n", (int)n_clips);
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
   tsm_config cfg;
   tsm_engine *e = NULL;
@@ -70,6 +175,11 @@ int main(int argc, char **argv) {
   if (strstr(tsm_last_error(NULL), "struct_size") == NULL) { fprintf(stderr, "no message\n"); return 4; }
   if (tsm_forward(NULL, NULL, TSM_MEM_HOST, TSM_LAYOUT_NTCHW, 1, NULL, NULL) != TSM_ERR_INVALID_ARG) return 5;
   tsm_destroy(NULL);
+  /* engine-less device entry points refuse NULL buffers before they touch the GPU */
+  if (tsm_preprocess(NULL, TSM_PIXEL_U8, 1, 8, 8, NULL, TSM_LAYOUT_NTHWC4, 8, 8, 0, NULL) != TSM_ERR_INVALID_ARG) return 11;
+  if (tsm_gather_clips(NULL, 1, 16, 0, 1, 0, 0, 1, 8, 8, 2, NULL, NULL) != TSM_ERR_INVALID_ARG) return 12;
+  if (tsm_scores_to_states(NULL, 1, 12, 1, 0.5f, NULL, NULL, NULL) != TSM_ERR_INVALID_ARG) return 13;
+  if (argc >= 5 && strcmp(argv[1], "pipeline") == 0) return pipeline(argv[2], argv[3], argv[4]);
   if (argc < 2 || strcmp(argv[1], "run") != 0) { printf("abi_c_smoke: error paths ok\n"); return 0; }
 
   cfg.struct_size = (int32_t)sizeof cfg; cfg.num_class = 12; cfg.num_segments = 8; cfg.height = 64; cfg.width = 64;

@@ -85,7 +85,8 @@ def _build_c_smoke(tmp_path):
     from workoutdetector_amd.build import LIB_PATH, PKG_DIR
     exe = str(tmp_path / 'abi_c_smoke')
     cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'),
-           os.path.join(ROOT, 'tests', 'abi_c_smoke.c'), '-o', exe, LIB_PATH, f'-Wl,-rpath,{PKG_DIR}']
+           os.path.join(ROOT, 'tests', 'abi_c_smoke.c'), '-o', exe, LIB_PATH, f'-Wl,-rpath,{PKG_DIR}',
+           '-L/opt/rocm/lib', '-lamdhip64', '-Wl,-rpath,/opt/rocm/lib']      # (hipMalloc / hipMemcpy for the device pipeline)
     subprocess.run(cmd, check=True, capture_output=True, text=True)
     return exe
 

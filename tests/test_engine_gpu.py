@@ -200,6 +200,51 @@ def test_c_program_runs_a_forward(hip_lib, tmp_path):
     assert 'forward ok' in out.stdout
 
 
+def test_c_program_runs_the_device_pipeline(hip_lib, tmp_path):
+    """the dataset loop's device pipeline driven from plain C99 -- tsm_preprocess -> tsm_gather_clips ->
+    tsm_forward(TSM_LAYOUT_NTHWC4, device memory) -> tsm_scores_to_states (tests/abi_c_smoke.c `pipeline`) -- against the
+    Python binding on the same weights and the same uint8 video: logits, states and top scores bit for bit."""
+    import struct
+    import subprocess
+    import torch
+    from tests.test_abi import _build_c_smoke
+    from workoutdetector_amd import _lib, engine
+    from workoutdetector_amd.weights import make_state_dict
+    sd = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in make_state_dict(3, 12).items()
+          if not k.endswith('num_batches_tracked')}
+    sd['fc.weight'] = sd['fc.weight'] * 40.0          # spread the softmax so that states are not all -1
+    frames, h, w, resize, crop = 43, 70, 90, 72, 64   # 6 clips, the last one zero-padded; non-square source
+    video = np.random.default_rng(9).integers(0, 256, (frames, h, w, 3), dtype=np.uint8)
+    with open(tmp_path / 'w.bin', 'wb') as f:
+        f.write(struct.pack('<i', len(sd)))
+        for k, v in sd.items():
+            f.write(struct.pack('<i', len(k)) + k.encode() + struct.pack('<i', v.ndim) + struct.pack(f'<{v.ndim}q', *v.shape))
+            f.write(v.tobytes())
+    with open(tmp_path / 'v.bin', 'wb') as f:
+        f.write(struct.pack('<5i', frames, h, w, resize, crop) + video.tobytes())
+    exe = _build_c_smoke(tmp_path)
+    out = subprocess.run([exe, 'pipeline', str(tmp_path / 'w.bin'), str(tmp_path / 'v.bin'), str(tmp_path / 'o.bin')],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and 'pipeline ok' in out.stdout, out.stdout + out.stderr
+    raw = open(tmp_path / 'o.bin', 'rb').read()
+    n_clips = struct.unpack_from('<i', raw)[0]
+    assert n_clips == (frames + 7) // 8
+    c_logits = np.frombuffer(raw, np.float32, n_clips * 12, 4).reshape(n_clips, 12)
+    c_states = np.frombuffer(raw, np.int32, n_clips, 4 + n_clips * 48)
+    c_top = np.frombuffer(raw, np.float32, n_clips, 4 + n_clips * 52)
+    # the same steps through the Python binding
+    eng = engine.TsmEngine(num_class=12, num_segments=8, height=crop, width=crop, max_clips=n_clips, state_dict=sd)
+    even = torch.cat([torch.from_numpy(video[0::2]), torch.zeros((1, h, w, 3), dtype=torch.uint8)]).cuda()
+    packed = engine.preprocess_frames(even, resize=resize, crop=crop, layout=_lib.LAYOUT_NTHWC4)
+    clips = engine.gather_clips(packed, 0, frames, 0, n_clips)
+    logits = eng.forward_device(clips, layout=_lib.LAYOUT_NTHWC4)
+    states, top = engine.scores_to_states(logits, threshold=0.1, return_top=True)
+    assert np.array_equal(c_logits, logits.cpu().numpy())
+    assert np.array_equal(c_states, states.cpu().numpy()) and np.array_equal(c_top, top.cpu().numpy())
+    assert (c_states >= 0).any(), c_states
+    eng.close()
+
+
 @pytest.mark.parametrize('dtype,t,div,h,w,ncls,rtol', [
     ('f32', 4, 16, 96, 128, 5, 1e-3),        # fold = C/16, non-square, odd class count
     ('f32', 3, 8, 64, 96, 2, 1e-3),          # odd segment count (the reference's factory default num_class=2)

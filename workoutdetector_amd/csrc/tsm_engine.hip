@@ -1118,8 +1118,9 @@ int tsm_gather_clips(const void *frames, int64_t n_frames, int64_t frame_bytes, 
   hipError_t st = tsm::launch_gather_clips(p, static_cast<hipStream_t>(stream));
   if (st != hipSuccess)
     return fail(nullptr, st == hipErrorInvalidValue ? TSM_ERR_INVALID_ARG : TSM_ERR_HIP,
-                st == hipErrorInvalidValue ? std::string("gather_clips: a clip of the range reads outside the frame buffer "
-                                                         "(or frame_bytes is not a multiple of 16, or more than 65535 rows)")
+                st == hipErrorInvalidValue ? std::string("gather_clips: a clip of the range reads outside the frame buffer, "
+                                                         "the pad frame is one of the range's video frames, or frame_bytes "
+                                                         "is not a multiple of 16")
                                            : std::string("gather_clips: ") + hipGetErrorString(st));
   return TSM_OK;
 }

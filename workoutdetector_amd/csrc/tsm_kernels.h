@@ -153,6 +153,7 @@ struct GatherParams {
   void *out;
   int64_t n_frames, frame_bytes, first_frame, total_frames, first_clip, pad_frame;
   int n_clips, n_segment, clip_step, clip_stride;
+  int64_t row0;   // first (clip, segment) row of this launch (set by launch_gather_clips: one launch cuts <= 65535 rows)
 };
 hipError_t launch_gather_clips(const GatherParams &p, hipStream_t s);
 

@@ -4239,12 +4239,13 @@ hipError_t launch_preprocess(const PreprocParams &p, hipStream_t s) {
 // the GPU idle at the head of every cold dataset job, profiles/r03_config4_gpu_gaps_pieces.txt).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gather_clips_kernel(const GatherParams p) {
-  const int row = blockIdx.y;                       // (clip, segment) of the output
-  const int c = row / p.n_segment, k = row - c * p.n_segment;
+  const int64_t row = p.row0 + blockIdx.y;          // (clip, segment) of the output
+  const int64_t c = row / p.n_segment;
+  const int k = (int)(row - c * p.n_segment);
   const int64_t src_frame = (int64_t)p.clip_step * (p.first_clip + c) + (int64_t)p.clip_stride * k;
   const int64_t j = src_frame < p.total_frames ? src_frame / p.clip_stride - p.first_frame : p.pad_frame;
   const uint4 *src = reinterpret_cast<const uint4 *>(static_cast<const char *>(p.frames) + j * p.frame_bytes);
-  uint4 *dst = reinterpret_cast<uint4 *>(static_cast<char *>(p.out) + (int64_t)row * p.frame_bytes);
+  uint4 *dst = reinterpret_cast<uint4 *>(static_cast<char *>(p.out) + row * p.frame_bytes);
   const int64_t n16 = p.frame_bytes / 16;
   for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 1024) {
     uint4 v[4];
@@ -4257,22 +4258,36 @@ __global__ void __launch_bounds__(256) gather_clips_kernel(const GatherParams p)
   }
 }
 
-hipError_t launch_gather_clips(const GatherParams &p, hipStream_t s) {
+hipError_t launch_gather_clips(const GatherParams &p_in, hipStream_t s) {
+  GatherParams p = p_in;
   if (!p.frames || !p.out || p.n_frames <= 0 || p.frame_bytes <= 0 || p.frame_bytes % 16 != 0 || p.n_clips <= 0 ||
       p.n_segment <= 0 || p.clip_step <= 0 || p.clip_stride <= 0 || p.clip_step % p.clip_stride != 0 ||
-      p.first_clip < 0 || p.first_frame < 0 || p.total_frames <= 0 || (int64_t)p.n_clips * p.n_segment > 65535)
+      p.first_clip < 0 || p.first_frame < 0 || p.total_frames <= 0)
     return hipErrorInvalidValue;
   // every index the kernel will form, checked here: the first and the last in-video position of the range, and the pad frame
   const int64_t lo = (int64_t)p.clip_step * p.first_clip;
   const int64_t hi = (int64_t)p.clip_step * (p.first_clip + p.n_clips - 1) + (int64_t)p.clip_stride * (p.n_segment - 1);
   if (lo >= p.total_frames) return hipErrorInvalidValue;                       // a clip starts inside its video
   const int64_t last = (hi < p.total_frames ? hi : p.total_frames - 1) / p.clip_stride - p.first_frame;
-  if (lo / p.clip_stride - p.first_frame < 0 || last >= p.n_frames) return hipErrorInvalidValue;
-  if (hi >= p.total_frames && (p.pad_frame < 0 || p.pad_frame >= p.n_frames)) return hipErrorInvalidValue;
+  const int64_t first = lo / p.clip_stride - p.first_frame;
+  if (first < 0 || last >= p.n_frames) return hipErrorInvalidValue;
+  // a padded tail reads the pad frame: it must lie in the buffer and must not be one of the range's own video frames (a
+  // mis-sized buffer or a wrong first_frame / total_frames pair would otherwise pass a real frame off as the zero frame)
+  if (hi >= p.total_frames && (p.pad_frame < 0 || p.pad_frame >= p.n_frames || (p.pad_frame >= first && p.pad_frame <= last)))
+    return hipErrorInvalidValue;
   const int64_t n16 = p.frame_bytes / 16;
   const unsigned gx = (unsigned)((n16 + 1023) / 1024 < 64 ? (n16 + 1023) / 1024 : 64);
-  hipLaunchKernelGGL(gather_clips_kernel, dim3(gx, (unsigned)(p.n_clips * p.n_segment)), dim3(256), 0, s, p);
-  return hipGetLastError();
+  // grid.y holds at most 65535 (clip, segment) rows: longer ranges are cut into several launches here, so that the limit
+  // is not a property of the C ABI
+  const int64_t rows = (int64_t)p.n_clips * p.n_segment;
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+    p.row0 = r0;
+    const int64_t ny = rows - r0 < 65535 ? rows - r0 : 65535;
+    hipLaunchKernelGGL(gather_clips_kernel, dim3(gx, (unsigned)ny), dim3(256), 0, s, p);
+    const hipError_t st = hipGetLastError();
+    if (st != hipSuccess) return st;
+  }
+  return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------------

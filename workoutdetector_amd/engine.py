@@ -427,13 +427,10 @@ def gather_clips(frames, first_frame: int, total_frames: int, first_clip: int, n
     if (not out.is_cuda or not out.is_contiguous() or out.device != frames.device
             or out.numel() * out.element_size() != n_clips * n_segment * frame_bytes):
         raise ValueError('out must be a contiguous CUDA tensor of n_clips * n_segment frames on the frames\' device')
-    per_call = max(1, 65535 // n_segment)       # one launch cuts at most 65535 (clip, segment) rows
-    for c0 in range(0, n_clips, per_call):
-        c1 = min(c0 + per_call, n_clips)
-        _lib.check(_lib.load().tsm_gather_clips(frames.data_ptr(), n, frame_bytes, int(first_frame), int(total_frames),
-                                                n - 1 if pad_frame is None else int(pad_frame), int(first_clip) + c0, c1 - c0,
-                                                n_segment, clip_step, clip_stride,
-                                                out.data_ptr() + c0 * n_segment * frame_bytes, _stream(frames)))
+    # (ranges of any length: the library cuts them into launches of <= 65535 rows itself)
+    _lib.check(_lib.load().tsm_gather_clips(frames.data_ptr(), n, frame_bytes, int(first_frame), int(total_frames),
+                                            n - 1 if pad_frame is None else int(pad_frame), int(first_clip), n_clips,
+                                            n_segment, clip_step, clip_stride, out.data_ptr(), _stream(frames)))
     return out
 
 
