@@ -25,7 +25,13 @@ Extra objects on the line:
                 (65.395 GFLOP/clip, SURVEY.md section 8d, all 53 conv launches + pool/head kernels).
   cpu_baseline  the CPU oracle (oracle/tsm_oracle.py, torch-CPU fp32, the same graph; the reference's
                 own onnxruntime CPU path cannot run here) timed on this box's host cores, batch 1 like
-                the reference (utils/inference_count.py:272), bounded to ~15 s
+                the reference (utils/inference_count.py:272), bounded to ~15 s; median (`value`) and best, with the CPU
+                model, the load average and torch's thread count beside them (a shared host: the figure moves with them)
+  parity        the logits the TIMED steps produced (the output of the last timed step; what
+                utils/inference_count.py:273-275 would hand to the counter), checked on rank 0 AFTER the timed region
+                against the CPU oracle on a few of the timed clips: max |err| / logit scale against the bar of the parity
+                tests (fp32 / split-bf16: rtol 1e-3 + 1e-5 of the scale, the fp32 oracle; bf16: 1e-2 of the scale and
+                the same arg-max, the bf16-storage oracle).  A failed check makes the run fail, not just the line.
 """
 import argparse
 import json
@@ -91,6 +97,7 @@ def cpu_baseline(sd_np, t, h, w, budget_s=15.0):
     from workoutdetector_amd.weights import to_torch
     cores = host_cores()
     torch.set_num_threads(cores)
+    load0 = os.getloadavg()
     sd = to_torch(sd_np)
     x = torch.randn(1, t, 3, h, w, generator=torch.Generator().manual_seed(0))
     tsm_oracle.tsm_forward(sd, x, n_segment=t)  # warm-up
@@ -112,11 +119,62 @@ def cpu_baseline(sd_np, t, h, w, budget_s=15.0):
         tsm_oracle.tsm_forward(sd, x8, n_segment=t)
         times8.append(time.perf_counter() - t0)
     times8.sort()
+    cpu_model = None
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.lower().startswith('model name'):
+                cpu_model = ln.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {'value': round(1.0 / med, 3), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
-            'batch8_value': round(8.0 / times8[len(times8) // 2], 3),
+            'best': round(1.0 / times[0], 3), 'worst': round(1.0 / times[-1], 3),
+            'batch8_value': round(8.0 / times8[len(times8) // 2], 3), 'batch8_best': round(8.0 / times8[0], 3),
+            'cpu_model': cpu_model, 'host_cpus': os.cpu_count(), 'torch_threads': torch.get_num_threads(),
+            'loadavg_before_after': [round(v, 2) for v in load0[:2]] + [round(v, 2) for v in os.getloadavg()[:2]],
+            'note': 'a shared host: the share of the cores this process really gets moves with the load average '
+                    '(1-min, 5-min before and after the sample); `best` is the least disturbed run',
             'sample': f'{len(times)} x 1 clip [1,{t},3,{h},{w}] fp32, batch 1 like the reference, median (`value`); '
                       f'{len(times8)} x 8 clips, median (`batch8_value`); torch-CPU oracle of the same graph '
                       f'(reference onnxruntime CPU path not runnable here)'}
+
+
+PARITY_CLIPS = 3     # clips of the timed batch held against the oracle (first, middle, last)
+
+
+def oracle_logits(sd_np, clips_cpu, t, dtypes):
+    """{'f32': fp32-oracle logits, 'bf16': bf16-storage-oracle logits} of a few of the timed clips (test infrastructure
+    used as the CHECKER of the timed output, after the timed region, on rank 0 only)."""
+    import torch
+    from oracle import tsm_oracle
+    from workoutdetector_amd.weights import to_torch
+    torch.set_num_threads(host_cores())
+    sd = to_torch(sd_np)
+    want = {}
+    if any(d in ('f32', 'bf16x3') for d in dtypes):
+        want['f32'] = tsm_oracle.tsm_forward(sd, clips_cpu, n_segment=t).numpy()
+    if 'bf16' in dtypes:
+        want['bf16'] = tsm_oracle.tsm_forward_bf16(sd, clips_cpu, n_segment=t).numpy()
+    return want
+
+
+def parity_of(got, want, dtype):
+    """The bars of the parity tests (tests/_util.py): fp32 / split-bf16 |err| <= 1e-3 |want| + 1e-5 scale against the
+    fp32 oracle; bf16 |err| <= 1e-2 scale and the same arg-max against the bf16-storage oracle."""
+    import numpy as np
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(want['bf16' if dtype == 'bf16' else 'f32'], dtype=np.float64)
+    scale = float(np.abs(ref).max())
+    err = np.abs(got - ref)
+    if dtype == 'bf16':
+        ok = bool(np.isfinite(got).all() and (err <= 1e-2 * scale).all() and (got.argmax(1) == ref.argmax(1)).all())
+        bar, against = 1e-2, 'bf16-storage oracle (oracle.tsm_oracle.tsm_forward_bf16), bar = 1e-2 of the logit scale + same arg-max'
+    else:
+        ok = bool(np.isfinite(got).all() and (err <= 1e-3 * np.abs(ref) + 1e-5 * scale).all())
+        bar, against = 1e-3, 'fp32 oracle (oracle.tsm_oracle.tsm_forward), bar = rtol 1e-3 + 1e-5 of the logit scale'
+    return {'clips_checked': int(got.shape[0]), 'max_err_over_scale': float('%.3g' % (err.max() / scale)), 'bar': bar,
+            'ok': ok, 'against': against, 'logit_scale': float('%.4g' % scale),
+            'what': 'logits written by the last TIMED step, compared after the timed region (rank 0)'}
 
 
 def _free_port():
@@ -197,6 +255,7 @@ def main():
     ap.add_argument('--segments', type=int, default=8)
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true', help='skip the oracle check of the timed logits (profiling runs)')
     ap.add_argument('--no-alt', action='store_true', help='skip the second run in the other precision mode')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16x3', 'bf16'],
                     help='f32: exact-fp32 MFMA; bf16x3: split-bf16 storage, 3 bf16 MFMAs per product')
@@ -309,6 +368,8 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         assert bool(torch.isfinite(out).all())
+        # the timed steps' own output, kept for the parity check below (a [world * B, 12] gather starts with this rank's rows)
+        timed_logits[dtype] = out[:B][parity_idx].detach().float().cpu().numpy()
         # Per-launch durations of the timed forwards (events were recorded inside the timed region; reading
         # them here keeps the host syncs out of it).
         per_launch = [eng.layer_times_ms(i) for i in range(n_timed)] if want_launch_times else []
@@ -339,7 +400,8 @@ def main():
         eng.close()
         return float(t_max.item()), per_launch, sorted(fwd_ev_ms)[len(fwd_ev_ms) // 2], tiles
 
-    exchange_us, step_ms, rank_ms = {}, {}, {}
+    exchange_us, step_ms, rank_ms, timed_logits = {}, {}, {}, {}
+    parity_idx = sorted({0, B // 2, B - 1})[:PARITY_CLIPS]
     elapsed, per_launch, fwd_ms, tiles = run_mode(args.dtype, True)
     alt = None
     if not args.no_alt:
@@ -347,6 +409,13 @@ def main():
         alt_elapsed, _, alt_fwd_ms, _ = run_mode(alt_dtype, False)
         alt = (alt_dtype, alt_elapsed, alt_fwd_ms)
 
+    parity = {}
+    if rank == 0 and not args.no_parity:
+        # Parity of what was TIMED, in this process: the CPU oracle on a few of the timed clips (outside the timed region)
+        want = oracle_logits(sd, clips[parity_idx].cpu(), T, list(timed_logits))
+        parity = {d: parity_of(g, want, d) for d, g in timed_logits.items()}
+        for d in parity:
+            parity[d]['clips'] = parity_idx
     if rank == 0:
         clips_total = B * world * args.steps
         value = clips_total / elapsed
@@ -426,6 +495,8 @@ def main():
             gbs = traffic_entry['forward_hbm_bytes'] / 1e9 / (fwd_ms / 1e3)
             line['roofline'].update({'forward_hbm_gbs': round(gbs, 1), 'forward_hbm_frac': round(gbs / PEAK_HBM_GBS, 4),
                                      'hbm_peak_gbs': PEAK_HBM_GBS})
+        if parity:
+            line['parity'] = parity[args.dtype]
         if rehearsal:
             line['rehearsal'] = True
         if collective:
@@ -440,7 +511,7 @@ def main():
         if alt is not None:
             a_dtype, a_elapsed, a_fwd = alt
             line['alt_precision'] = {
-                'dtype': a_dtype, 'value': round(clips_total / a_elapsed, 2), 'unit': 'clips/s',
+                'dtype': a_dtype, 'value': None if rehearsal else round(clips_total / a_elapsed, 2), 'unit': 'clips/s',
                 'ms_per_step': round(1e3 * a_elapsed / args.steps, 4), 'forward_kernel_ms': round(a_fwd, 4),
                 'forward_algorithmic_tflops': round(gflop * B / a_fwd, 2),
                 'note': ('same engine, same inputs, same steps/warmup, TSM_DTYPE_BF16X3: split-bf16 storage (hi/lo), '
@@ -448,9 +519,14 @@ def main():
                          'same parity tests (logits within 5e-6 of the fp32 oracle, bar 1e-3; tests/test_bf16x3_gpu.py); '
                          'not the headline because it is not bit-level fp32 arithmetic')
                         if a_dtype == 'bf16x3' else 'exact-fp32 MFMA mode of the same engine'}
+            if a_dtype in parity:
+                line['alt_precision']['parity'] = parity[a_dtype]
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, T, H, W)
         print(json.dumps(line), flush=True)
+        bad = [d for d, q in parity.items() if not q['ok']]
+        if bad:
+            raise SystemExit(f'parity check of the timed logits FAILED for {bad}: {[parity[d] for d in bad]}')
     if collective:
         dist.barrier()
         dist.destroy_process_group()
