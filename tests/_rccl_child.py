@@ -66,7 +66,7 @@ def main(tmp, port):
     ic.inference_dataset(eng, ['test'], plain, checkpoint='seed0', data_root=root, batch_clips=8)
     assert calls['n'] == 2
     tdist.set_force_collective(True)
-    for shard, expect_calls in (('clips', 3), ('videos', 6), ('global', 2)):     # one gather per video / meta + logits per round / video table + logits per JOB
+    for shard, expect_calls in (('clips', 3), ('videos', 6), ('global', 3)):     # one gather per video / meta + logits per round / plan checksum + video table + logits per JOB
         before = calls['n']
         out_dir = os.path.join(tmp, shard)
         ic.inference_dataset(eng, ['test'], out_dir, checkpoint='seed0', data_root=root, batch_clips=8, shard=shard)

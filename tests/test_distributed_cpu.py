@@ -137,8 +137,9 @@ def _dataset_global_worker(rank, world, root, out_dir, batch):
     dist.all_gather_into_tensor = counting
     model = StubModel()
     ic.inference_dataset(model, ['test'], out_dir, checkpoint='stub', data_root=root, batch_clips=batch)   # default shard
-    # no collective inside the loop: the whole job exchanges twice (video table, then the logits), whatever its size
-    assert calls['n'] == 2, calls
+    # no collective inside the loop: the plan checksum up front, then the whole job exchanges twice (video table + status
+    # words, then the logits), whatever its size
+    assert calls['n'] == 3, calls
     open(os.path.join(out_dir, f'calls{rank}'), 'w').write(str(model.calls))
 
 
@@ -182,6 +183,50 @@ def test_globally_sharded_inference_dataset_equals_single_process(tmp_path, gold
     ic.inference_dataset(StubModel(), ['test'], alone, checkpoint='stub', data_root=str(root), shard='global', batch_clips=5)
     for f in files:
         assert open(os.path.join(single, f)).read() == open(os.path.join(alone, f)).read(), f
+
+
+def _dataset_global_failing_worker(rank, world, root, out_dir):
+    """Rank 1's model raises on its second forward: EVERY rank must come out of inference_dataset with an exception (rank 1
+    with its own, the others with one naming rank 1) instead of blocking in the final all-gather."""
+    from tests._stub import StubModel
+    from workoutdetector_amd import inference_count as ic
+
+    class Flaky(StubModel):
+        def run(self, output_names, feed):
+            if rank == 1 and self.calls >= 1:
+                raise OSError('decoder died')
+            return super().run(output_names, feed)
+
+    try:
+        ic.inference_dataset(Flaky(), ['test'], out_dir, checkpoint='stub', data_root=root, batch_clips=4)
+    except OSError as exc:
+        assert rank == 1 and 'decoder died' in str(exc)
+        open(os.path.join(out_dir, f'raised{rank}'), 'w').write('own')
+    except RuntimeError as exc:
+        assert rank != 1 and 'rank(s) [1] failed' in str(exc), str(exc)
+        open(os.path.join(out_dir, f'raised{rank}'), 'w').write('peer')
+
+
+def test_global_sharding_failure_on_one_rank_reaches_every_rank(tmp_path, golden_dir):
+    """with no collective inside the loop, a rank that raises must still enter the final exchange (error marker
+    in the video table) -- the other ranks then raise too instead of waiting for ever; and ranks whose shard plans differ
+    fail before any work."""
+    import pandas as pd
+    from tests._stub import synthetic_video
+    from workoutdetector_amd.repcount import CLASSES
+    anno = pd.read_csv(f'{golden_dir}/repcount_annotation.csv', index_col=0)
+    rows = anno[(anno['split'] == 'test') & anno['class_'].isin(CLASSES)].head(6).copy()
+    rows['name'] = [n.replace('.mp4', '.npy') for n in rows['name']]
+    root = tmp_path / 'RepCount'
+    (root / 'videos' / 'test').mkdir(parents=True)
+    rows.to_csv(root / 'annotation.csv')
+    for i, name in enumerate(rows['name']):
+        np.save(root / 'videos' / 'test' / name, synthetic_video(i, GLOBAL_FRAMES[i], 40, 30))
+    out_dir = str(tmp_path / 'out')
+    os.makedirs(out_dir)
+    _spawn(_dataset_global_failing_worker, str(root), out_dir, world=3)
+    assert sorted(f for f in os.listdir(out_dir) if f.startswith('raised')) == ['raised0', 'raised1', 'raised2']
+    assert open(os.path.join(out_dir, 'raised1')).read() == 'own' and open(os.path.join(out_dir, 'raised0')).read() == 'peer'
 
 
 def _dataset_global_anon_worker(rank, world, root, out_dir):

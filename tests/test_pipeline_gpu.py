@@ -163,6 +163,18 @@ def test_stream_batcher_on_gpu_engine(probe_engine):
     ev_cap, res_cap = play_res(32, 40, max_pinned_bytes=300_000, max_free_per_shape=1)
     ev32, res32 = play_res(32, 40)
     assert ev_cap == ev32 and res_cap == res32
+    # open / close cycles at a resolution another open stream still uses must not grow the idle list past the cap
+    sb = StreamBatcher(eng, max_batch=4, max_free_per_shape=2)
+    sb.push('keep', vids['a'][0])
+    win = 8 * 90 * 52 * 3
+    for i in range(6):
+        for t in range(11):                       # one complete window that never runs + a half-filled one
+            sb.push(('x', i), vids['a'][t])
+        sb.close(('x', i))
+        idle = sb._free.get((90, 52, 3), [])
+        assert len(idle) <= 2 and sb.pinned_bytes == (1 + len(idle)) * win, (i, len(idle), sb.pinned_bytes)
+    sb.close('keep')
+    assert sb.pinned_bytes == 0 and not sb._free
     ev32, res32 = _play_plain(StreamBatcher, eng, vids, 32, 40)          # 5 windows x 3 streams per step -> batches of up to 15 mixed-size windows
     ev1, res1 = _play_plain(StreamBatcher, eng, vids, 1, 8)
     assert ev32 == ev1 and res32 == res1

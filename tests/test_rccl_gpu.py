@@ -44,7 +44,7 @@ def test_one_rank_nccl_group_drives_the_collective_branch(hip_lib, tmp_path):
                          capture_output=True, text=True, env=_env(), timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     rep = _last_json(out.stdout)
-    assert rep['ok'] and rep['backend'] == 'nccl' and rep['world'] == 1 and rep['collective_calls'] == 13
+    assert rep['ok'] and rep['backend'] == 'nccl' and rep['world'] == 1 and rep['collective_calls'] == 14
 
 
 def test_bench_step_through_a_one_rank_rccl_group(hip_lib):

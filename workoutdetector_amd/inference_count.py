@@ -157,11 +157,17 @@ class _PinnedPool:
                 self.cv.wait()
             self.taken[i] = True
             ev, self.busy[i] = self.busy[i], None
-        if ev is not None:
-            ev.synchronize()
-        if self.bufs[i] is None or self.bufs[i].numel() < nbytes:
-            self.bufs[i] = None                                  # free before growing
-            self.bufs[i] = torch.empty(max(nbytes, 1 << 20) * 5 // 4, dtype=torch.uint8, pin_memory=True)
+        try:
+            if ev is not None:
+                ev.synchronize()
+            if self.bufs[i] is None or self.bufs[i].numel() < nbytes:
+                self.bufs[i] = None                              # free before growing
+                self.bufs[i] = torch.empty(max(nbytes, 1 << 20) * 5 // 4, dtype=torch.uint8, pin_memory=True)
+        except BaseException:
+            # (a failed event wait or pinned allocation: the callers' try/finally only starts once take() has returned,
+            #  so the slot is handed back here -- the next taker must get an error or a buffer, never an endless wait)
+            self.release(i, None)
+            raise
         return self.bufs[i][:nbytes], i
 
     def release(self, slot: int, event: Optional[object]) -> None:
@@ -640,11 +646,25 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
     with full cross-video batches and NO collective inside the loop, and the job ends with one exchange: an
     all-gather of the per-video [index, frames, clips] table and ONE padded all-gather of the per-clip logits
     ``[clips_on_rank, num_class]`` (returned per video on every rank).  Each rank writes the JSON files of its own videos
-    while its GPU works on the videos behind them."""
+    while its GPU works on the videos behind them -- ``out_dir`` must therefore be ONE directory all ranks see (the ranks
+    of one node always do; a multi-node job needs a shared file system, or ``shard='clips'`` / ``'videos'``, whose files
+    are all written by rank 0).
+
+    Failure behaviour: the plan is computed by every rank from its own view of the dataset, so the ranks compare a
+    checksum of it BEFORE any work (a rank that sees other frame counts fails the job in its first second, on every
+    rank, instead of after the last video); and a rank whose loop raises still enters the final exchange, with an error
+    marker in the video table, so that the others raise too instead of blocking in an all-gather that never completes."""
     rank, world = tdist.world_info()
     dev = _engine_device(model)
     counts = [estimated_clips(it, frame_counter) for it in items]
     owner = tdist.plan_video_shards(counts, world)
+    if tdist.collective_enabled():
+        import zlib
+        sig = torch.tensor([[zlib.crc32(repr((owner, counts)).encode()), len(items)]], dtype=torch.int64)
+        sigs = tdist.all_gather_logits(sig.to(dev) if dev is not None and tdist.on_rccl() else sig).cpu()
+        if not bool((sigs == sigs[0]).all()):
+            raise RuntimeError(f'shard plan differs between ranks (checksum, videos) = {sigs.tolist()}: every rank must '
+                               f'see the same dataset and frame counts (rank {rank})')
     mine = [v for v in range(len(items)) if owner[v] == rank]
     # (the stager's worker starts on the first video here, before the host-side setup below)
     pieces = prefetch_pieces(model, ((v, (lambda p=items[v].video_path: reader(p))) for v in mine))
@@ -660,7 +680,8 @@ def _run_global(model, items: list, mine: List[int], counts: List[int], pieces, 
     batcher = _ClipBatcher(model, batch_clips)
     writer = _ScoreWriter(out_dir, checkpoint, sum(counts[v] for v in mine) + 8 * len(mine),
                           getattr(model, 'num_class', None), pin=dev is not None)
-    meta = torch.full((len(items), 4), -1, dtype=torch.int64)      # rows of MY videos: [video index, frames, clips, classes]
+    # rows of MY videos: [video index, frames, clips, classes]; the last row is this rank's status word (0 = loop completed)
+    meta = torch.full((len(items) + 1, 4), -1, dtype=torch.int64)
     slot_of = {v: i for i, v in enumerate(mine)}
     whole = 0                                                      # videos of ``mine`` whose last piece has been queued
     handed = 0                                                     # ... already with the writer (in order)
@@ -674,22 +695,29 @@ def _run_global(model, items: list, mine: List[int], counts: List[int], pieces, 
             handed += 1
         writer.poll()
 
-    for v, st, last in pieces:
-        slot = slot_of[v]
-        done = max(0, int(meta[slot, 2]))
-        meta[slot, :3] = torch.tensor([v, st.total, done + st.hi - st.lo])
-        if st.hi > st.lo:
-            batcher.add(v, *_staged_clips(model, st, transform), st=st)
-        else:
-            batcher.rows.setdefault(v, [])
-        if last:
-            whole = slot + 1
-        hand_over(False)
-    batcher.flush()
-    hand_over(True)
-    per_video = writer.drain()                                     # host rows of my videos, in ``mine`` order
+    failure: Optional[BaseException] = None
+    per_video: List[torch.Tensor] = []
+    try:
+        for v, st, last in pieces:
+            slot = slot_of[v]
+            done = max(0, int(meta[slot, 2]))
+            meta[slot, :3] = torch.tensor([v, st.total, done + st.hi - st.lo])
+            if st.hi > st.lo:
+                batcher.add(v, *_staged_clips(model, st, transform), st=st)
+            else:
+                batcher.rows.setdefault(v, [])
+            if last:
+                whole = slot + 1
+            hand_over(False)
+        batcher.flush()
+        hand_over(True)
+        per_video = writer.drain()                                 # host rows of my videos, in ``mine`` order
+    except Exception as exc:                                       # (reader error, OOM, ...): still take part in the exchange below
+        if not tdist.collective_enabled():
+            raise
+        failure = exc
     num_class = getattr(model, 'num_class', None) or (int(per_video[0].shape[1]) if per_video else 0)
-    local = (torch.cat([t.reshape(-1, num_class) for t in per_video], dim=0) if per_video
+    local = (torch.cat([t.reshape(-1, num_class) for t in per_video], dim=0) if per_video and failure is None
              else torch.empty((0, num_class), dtype=torch.float32))
     if not tdist.collective_enabled():
         out, pos = {}, 0
@@ -700,7 +728,14 @@ def _run_global(model, items: list, mine: List[int], counts: List[int], pieces, 
         return out
     on_gpu = dev is not None and tdist.on_rccl()
     meta[:len(mine), 3] = num_class      # (a rank without videos does not know the class count: it rides in the table)
-    metas = tdist.all_gather_logits(meta.to(dev) if on_gpu else meta).cpu().reshape(world, len(items), 4)
+    meta[-1] = torch.tensor([0 if failure is None else 1, 0, 0, 0])
+    metas = tdist.all_gather_logits(meta.to(dev) if on_gpu else meta).cpu().reshape(world, len(items) + 1, 4)
+    failed = [r for r in range(world) if int(metas[r, -1, 0]) != 0]
+    if failed:       # every rank sees the same table: all of them stop here, none is left waiting in the logits all-gather
+        if failure is not None:
+            raise failure
+        raise RuntimeError(f'rank(s) {failed} failed in their share of the dataset job; no logits were exchanged (rank {rank})')
+    metas = metas[:, :-1]
     per = max(1, int(metas[:, :, 2].clamp(min=0).sum(dim=1).max()))
     ncls = max(num_class, int(metas[:, :, 3].max()))
     pad = torch.zeros((per, ncls), dtype=torch.float32)

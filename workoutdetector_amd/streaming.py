@@ -104,14 +104,21 @@ class StreamBatcher:
             if wait:
                 ev.synchronize()
             if ev.query():
-                free = self._free.setdefault(tuple(buf.shape[1:]), [])
-                if buf.is_pinned() and len(free) < self.max_free_per_shape:
-                    free.append(buf)
-                elif buf.is_pinned():
-                    self.pinned_bytes -= buf.numel()
+                self._give_back(buf)
             else:
                 still.append((ev, buf))
         self._inflight = still
+
+    def _give_back(self, buf: torch.Tensor) -> None:
+        """An idle window buffer returns to its shape's free list while that list is below ``max_free_per_shape``; beyond
+        the cap (and for pageable fallback buffers) it is dropped and its page-locked bytes leave the budget."""
+        if not buf.is_pinned():
+            return
+        free = self._free.setdefault(tuple(buf.shape[1:]), [])
+        if len(free) < self.max_free_per_shape:
+            free.append(buf)
+        else:
+            self.pinned_bytes -= buf.numel()
 
     def _take_window(self, frame_shape: Tuple[int, ...]) -> torch.Tensor:
         """A uint8 [8,H,W,3] window buffer: a recycled page-locked one if one of this size is free, a newly pinned one
@@ -142,8 +149,7 @@ class StreamBatcher:
         """Drop a stream (an incomplete last window is discarded, like the reference) -> (count, reps)."""
         st = self.streams.pop(stream_id)
         for buf in ([st.cur] if st.cur is not None else []) + [w for w in st.windows if isinstance(w, torch.Tensor)]:
-            if buf.is_pinned():                              # half-filled / never-run windows go back to the pool
-                self._free.setdefault(tuple(buf.shape[1:]), []).append(buf)
+            self._give_back(buf)                             # half-filled / never-run windows: the same capped path as _recycle
         self._trim_free()
         return st.counter.count, list(st.counter.reps)
 
