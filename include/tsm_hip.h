@@ -12,6 +12,8 @@
  *       model.run(None, {input_name: float32[1,8,3,224,224]}) -> [float32[1,num_class]]
  *       workoutdetector/utils/inference_count.py:273-275, scripts/eval_classification.py:43-44
  *       == TSM.forward(x[B*T,3,H,W]) -> [B,num_class]   workoutdetector/models/tsm.py:409-419
+ *   tsm_tune               (no counterpart: onnxruntime optimises its graph inside InferenceSession(), :620; this is the
+ *                          engine's per-batch-size kernel selection, made callable ahead of the first request)
  *   tsm_forward_tap        (parity tests) activation after a named stage of TSM.forward
  *   tsm_temporal_shift     TemporalShift.shift          workoutdetector/models/tsm.py:35-50
  *   tsm_conv_bn_act        one conv + BatchNorm(eval) [+ residual] [+ ReLU] of the torchvision
@@ -37,7 +39,7 @@
  *     exception: the FIRST tsm_forward of a new power-of-two bucket of n_clips tunes its kernels first (unless
  *     TSM_AUTOTUNE=0, or TSM_TUNE_CACHE names a file that already holds this bucket): it times every candidate on the
  *     real launches, which synchronises with `stream` about a hundred times and takes a few hundred ms, so that call is
- *     neither asynchronous nor legal inside a stream capture.  Run one forward per bucket at start-up (TsmEngine.warmup
+ *     neither asynchronous nor legal inside a stream capture.  Call tsm_tune per bucket at start-up (TsmEngine.warmup
  *     in the Python host) before capturing a graph or relying on enqueue-only behaviour; every later call of that
  *     bucket allocates nothing, synchronises nothing and is capture-safe.
  *   - Activations inside the engine are NHWC fp32.
@@ -51,7 +53,7 @@
 extern "C" {
 #endif
 
-#define TSM_ABI_VERSION 5 /* 5: tsm_gather_clips; 4: tsm_scores_to_states; tile codes lost the tail field; TSM_* variables read in tsm_create only */
+#define TSM_ABI_VERSION 6 /* 6: tsm_tune, per-user default tune cache; 5: tsm_gather_clips; 4: tsm_scores_to_states; tile codes lost the tail field; TSM_* variables read in tsm_create only */
 
 typedef enum tsm_status {
   TSM_OK = 0,
@@ -129,6 +131,17 @@ int tsm_finalize(tsm_engine *e);
  * logits: float32 [n_clips, num_class] in the same memkind.  Raw scores (before softmax). */
 int tsm_forward(tsm_engine *e, const void *clips, int32_t memkind, int32_t layout, int32_t n_clips,
                 float *logits, void *stream);
+
+/* Tune the kernels of the bucket `n_clips` falls into NOW (synchronous: a few hundred ms of timed launches on the
+ * engine's own zeroed input buffer; no caller memory is touched), or read the choices from the tune cache file: what
+ * the first tsm_forward of that bucket would otherwise do inside the call.  A no-op when the bucket is already tuned or
+ * TSM_AUTOTUNE=0.  Call it at start-up -- a service before it takes requests, a dataset job while its first frames are
+ * still being decoded (workoutdetector_amd/inference_count.py does) -- for every batch size that will occur; every
+ * tsm_forward(TSM_MEM_DEVICE) afterwards only enqueues.
+ * Tune cache: TSM_TUNE_CACHE=<file>, default $XDG_CACHE_HOME/tsm_hip/tune_cache.txt (else ~/.cache/tsm_hip/...); lines
+ * are keyed by ABI, library build, device, geometry and dtype, so a second process (or the other ranks of a job) skips
+ * the timing pass; TSM_TUNE_CACHE= (empty), 0 or off disables the file. */
+int tsm_tune(tsm_engine *e, int32_t n_clips, void *stream);
 
 /* Same as tsm_forward but stops after `stage` and returns that activation (NHWC fp32) in
  * `out` (capacity in floats); shape [N*T, H, W, C] written to out_shape[4].

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The library's default tune cache (~/.cache/tsm_hip/tune_cache.txt) would carry tile choices from one test process to
+# the next; tests that exercise the cache name their own file.
+os.environ.setdefault('TSM_TUNE_CACHE', 'off')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

@@ -37,7 +37,7 @@ def test_header_symbols_are_exported(lib):
 
 def test_abi_version_and_config_layout(lib):
     from workoutdetector_amd import _lib
-    assert lib.tsm_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.tsm_abi_version() == _lib.ABI_VERSION == 6
     assert ctypes.sizeof(_lib.TsmConfig) == 40          # 10 x int32, matches struct tsm_config
 
 

@@ -8,7 +8,7 @@ from typing import Optional
 
 from .build import LIB_PATH
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 MEM_HOST, MEM_DEVICE = 0, 1
 LAYOUT_NTCHW, LAYOUT_NTHWC, LAYOUT_NTHWC4, LAYOUT_NTHWC8S, LAYOUT_NTHWC8B = 0, 1, 2, 3, 4
@@ -33,7 +33,7 @@ class TsmError(RuntimeError):
 
 
 EXPORTS = ('tsm_abi_version', 'tsm_create', 'tsm_destroy', 'tsm_last_error', 'tsm_set_tensor', 'tsm_finalize',
-           'tsm_forward', 'tsm_forward_tap', 'tsm_last_forward_ms', 'tsm_set_layer_timing', 'tsm_layer_times', 'tsm_conv_tiles', 'tsm_temporal_shift', 'tsm_conv_bn_act',
+           'tsm_forward', 'tsm_tune', 'tsm_forward_tap', 'tsm_last_forward_ms', 'tsm_set_layer_timing', 'tsm_layer_times', 'tsm_conv_tiles', 'tsm_temporal_shift', 'tsm_conv_bn_act',
            'tsm_maxpool3x3s2', 'tsm_head', 'tsm_preprocess', 'tsm_gather_clips', 'tsm_scores_to_states')
 
 _lib: Optional[C.CDLL] = None
@@ -89,6 +89,8 @@ def load() -> C.CDLL:
     lib.tsm_maxpool3x3s2.argtypes = [fp, fp, i32, i32, i32, i32, vp]
     lib.tsm_preprocess.restype = C.c_int
     lib.tsm_preprocess.argtypes = [vp, i32, i32, i32, i32, fp, i32, i32, i32, i32, vp]
+    lib.tsm_tune.restype = C.c_int
+    lib.tsm_tune.argtypes = [vp, i32, vp]
     lib.tsm_gather_clips.restype = C.c_int
     lib.tsm_gather_clips.argtypes = [vp, i64, i64, i64, i64, i64, i64, i32, i32, i32, i32, vp, vp]
     lib.tsm_head.restype = C.c_int

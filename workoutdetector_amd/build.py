@@ -19,7 +19,11 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), 'include')
 # (TSM_LIB_PATH / TSM_BUILD_DEFS: tooling hooks for A/B builds of one kernel variant against another, e.g.
 #  TSM_LIB_PATH=.../libtsm_hip_v1.so TSM_BUILD_DEFS='-DTSM_256_SCHED=1' python -m workoutdetector_amd.build --force)
 LIB_PATH = os.environ.get('TSM_LIB_PATH') or os.path.join(PKG_DIR, 'libtsm_hip.so')
-SOURCES = ['tsm_kernels.hip', 'tsm_engine.hip']
+# One translation unit per kernel family (csrc/tsm_device.h lists them): objects are rebuilt only when their own source or
+# a header changed, in parallel, then linked.
+SOURCES = ['tsm_igemm.hip', 'tsm_bf16_256.hip', 'tsm_ws.hip', 'tsm_bneck.hip', 'tsm_conv31.hip', 'tsm_fused23.hip',
+           'tsm_stem.hip', 'tsm_ops.hip', 'tsm_engine.hip']
+OBJ_DIR = os.path.join(CSRC, 'obj')
 ARCH = 'gfx950'
 
 
@@ -31,7 +35,7 @@ def _hipcc() -> str:
 
 
 def _deps() -> List[str]:
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
     deps.append(os.path.join(INCLUDE, 'tsm_hip.h'))
     return deps
 
@@ -57,17 +61,51 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
+def _headers() -> List[str]:
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(INCLUDE, 'tsm_hip.h')]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
-    cmd = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared'] + os.environ.get('TSM_BUILD_DEFS', '').split() + \
-          ['-I', INCLUDE, '-o', LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    defs = os.environ.get('TSM_BUILD_DEFS', '').split()
+    # A/B builds (TSM_LIB_PATH / TSM_BUILD_DEFS) keep their objects apart from the product's
+    tag = '' if not (defs or os.environ.get('TSM_LIB_PATH')) else '_' + hashlib_tag(' '.join(defs) + LIB_PATH)
+    obj_dir = OBJ_DIR + tag
+    os.makedirs(obj_dir, exist_ok=True)
+    newest_header = max(os.path.getmtime(h) for h in _headers())
+    base = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC'] + defs + ['-I', INCLUDE]
+    jobs = []
+    for src in SOURCES:
+        path, obj = os.path.join(CSRC, src), os.path.join(obj_dir, src.replace('.hip', '.o'))
+        # the engine object carries the build id that keys the tune cache: rebuilt whenever anything changed
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header) \
+            or src == 'tsm_engine.hip'
+        if stale:
+            cmd = base + ([f'-DTSM_BUILD_ID="{csrc_sha16()}"'] if src == 'tsm_engine.hip' else []) + ['-c', path, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    failed = []
+    for src, proc in jobs:
+        out, err = proc.communicate()
+        if proc.returncode != 0:
+            failed.append(f'{src} ({proc.returncode}):\n{out}\n{err}')
+    if failed:
+        raise RuntimeError('hipcc failed: ' + '\n'.join(failed))
+    cmd = [_hipcc(), f'--offload-arch={ARCH}', '-fPIC', '-shared', '-o', LIB_PATH] + \
+          [os.path.join(obj_dir, s.replace('.hip', '.o')) for s in SOURCES]
     if verbose:
         print(' '.join(cmd), flush=True)
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError(f'hipcc failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}')
+        raise RuntimeError(f'link failed ({proc.returncode}):\n{proc.stdout}\n{proc.stderr}')
     return LIB_PATH
+
+
+def hashlib_tag(text: str) -> str:
+    import hashlib
+    return hashlib.sha256(text.encode()).hexdigest()[:10]
 
 
 if __name__ == '__main__':

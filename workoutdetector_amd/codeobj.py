@@ -1,6 +1,6 @@
 """Resource figures of the BUILT gfx950 code object: registers, LDS, scratch and the occupancy they allow.
 
-``libtsm_hip.so`` carries its device code as a clang offload bundle in ``.hip_fatbin``; the gfx950 entry is an ELF whose
+``libtsm_hip.so`` carries its device code as clang offload bundles in ``.hip_fatbin`` (one per translation unit); a gfx950 entry is an ELF whose
 ``NT_AMDGPU_METADATA`` note is a msgpack document with one record per kernel (``.vgpr_count`` -- the unified register
 count, accumulation registers included --, ``.agpr_count``, ``.sgpr_count``, ``.group_segment_fixed_size`` = static LDS,
 ``.private_segment_fixed_size`` = scratch, spill counts).  Several kernels of this library sit right at a budget (the
@@ -23,22 +23,27 @@ SIMDS_PER_CU = 4
 MAX_WAVES_PER_SIMD = 8
 
 
-def _gfx950_elf(lib_path: str) -> bytes:
+def _gfx950_elfs(lib_path: str) -> List[bytes]:
+    """The gfx950 code object of every offload bundle in the library: one bundle per translation unit (csrc/tsm_*.hip)."""
     data = open(lib_path, 'rb').read()
     magic = b'__CLANG_OFFLOAD_BUNDLE__'
-    base = data.find(magic)
+    elfs, base = [], data.find(magic)
     if base < 0:
         raise ValueError(f'{lib_path}: no uncompressed clang offload bundle (.hip_fatbin)')
-    n, = struct.unpack_from('<Q', data, base + len(magic))
-    off = base + len(magic) + 8
-    for _ in range(n):
-        o, size, tl = struct.unpack_from('<QQQ', data, off)
-        off += 24
-        triple = data[off:off + tl].decode()
-        off += tl
-        if 'gfx950' in triple and size:
-            return data[base + o:base + o + size]
-    raise ValueError(f'{lib_path}: no gfx950 code object in the bundle')
+    while base >= 0:
+        n, = struct.unpack_from('<Q', data, base + len(magic))
+        off = base + len(magic) + 8
+        for _ in range(n):
+            o, size, tl = struct.unpack_from('<QQQ', data, off)
+            off += 24
+            triple = data[off:off + tl].decode()
+            off += tl
+            if 'gfx950' in triple and size:
+                elfs.append(data[base + o:base + o + size])
+        base = data.find(magic, base + len(magic))
+    if not elfs:
+        raise ValueError(f'{lib_path}: no gfx950 code object in the bundles')
+    return elfs
 
 
 def kernel_metadata(lib_path: Optional[str] = None) -> Dict[str, dict]:
@@ -46,22 +51,22 @@ def kernel_metadata(lib_path: Optional[str] = None) -> Dict[str, dict]:
     import msgpack
     if lib_path is None:
         from .build import LIB_PATH as lib_path      # noqa: N811
-    elf = _gfx950_elf(lib_path)
-    shoff, = struct.unpack_from('<Q', elf, 0x28)
-    shentsize, shnum, _ = struct.unpack_from('<HHH', elf, 0x3A)
     records: List[dict] = []
-    for k in range(shnum):
-        sh = struct.unpack_from('<IIQQQQIIQQ', elf, shoff + k * shentsize)
-        if sh[1] != 7:                               # SHT_NOTE
-            continue
-        pos, end = sh[4], sh[4] + sh[5]
-        while pos < end:
-            namesz, descsz, typ = struct.unpack_from('<III', elf, pos)
-            pos += 12 + ((namesz + 3) & ~3)
-            desc = elf[pos:pos + descsz]
-            pos += (descsz + 3) & ~3
-            if typ == 32:                            # NT_AMDGPU_METADATA
-                records += msgpack.unpackb(desc, raw=False)['amdhsa.kernels']
+    for elf in _gfx950_elfs(lib_path):
+        shoff, = struct.unpack_from('<Q', elf, 0x28)
+        shentsize, shnum, _ = struct.unpack_from('<HHH', elf, 0x3A)
+        for k in range(shnum):
+            sh = struct.unpack_from('<IIQQQQIIQQ', elf, shoff + k * shentsize)
+            if sh[1] != 7:                               # SHT_NOTE
+                continue
+            pos, end = sh[4], sh[4] + sh[5]
+            while pos < end:
+                namesz, descsz, typ = struct.unpack_from('<III', elf, pos)
+                pos += 12 + ((namesz + 3) & ~3)
+                desc = elf[pos:pos + descsz]
+                pos += (descsz + 3) & ~3
+                if typ == 32:                            # NT_AMDGPU_METADATA
+                    records += msgpack.unpackb(desc, raw=False).get('amdhsa.kernels', [])
     names = [r['.name'] for r in records]
     demangled = subprocess.run(['c++filt'] + names, capture_output=True, text=True).stdout.splitlines() \
         if names else []

@@ -2,14 +2,17 @@
 //
 // Owns: packed weights (BatchNorm folded, K-major), an NHWC fp32 activation workspace sized for
 // max_clips, one HIP stream, two timing events.  The forward is a fixed schedule of kernel launches
-// (tsm_kernels.hip); nothing here falls back to a CPU path.
+// (csrc/tsm_*.hip, one file per kernel family: tsm_device.h lists them); nothing here falls back to a CPU path.
 //
 // Reference behaviour mirrored: workoutdetector/models/tsm.py:409-419 (TSM.forward), :125-137
 // (shift in front of every Bottleneck.conv1), :451-473 (state-dict naming); torchvision-0.13
 // ResNet-50 v1.5 (stride on conv2, BN eps 1e-5).
 #include <hip/hip_runtime.h>
 
+#include <sys/stat.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +24,10 @@
 #include "../../include/tsm_hip.h"
 #include "tsm_host_util.h"
 #include "tsm_kernels.h"
+
+#ifndef TSM_BUILD_ID   // workoutdetector_amd/build.py passes the sha of csrc/; a hand build falls back to its own time stamp
+#define TSM_BUILD_ID __DATE__ "/" __TIME__
+#endif
 
 namespace {
 
@@ -225,6 +232,22 @@ tsm::ConvParams make_params(const ConvLayer &c, const float *x, const float *res
   p.T = T; p.fold = T > 0 ? c.cp / shift_div : 0;
   p.kseg_len = res ? 0 : c.kseg;   // (no layer with a residual has a long K; the per-op entry point passes kseg = 0)
   return p;
+}
+
+// $XDG_CACHE_HOME/tsm_hip/tune_cache.txt, else $HOME/.cache/tsm_hip/tune_cache.txt ("" when neither is set or the
+// directory cannot be made: no cache, never an error).
+std::string default_tune_cache_path() {
+  std::string base;
+  if (const char *x = getenv("XDG_CACHE_HOME")) base = x;
+  if (base.empty()) {
+    const char *h = getenv("HOME");
+    if (!h || !*h) return "";
+    base = std::string(h) + "/.cache";
+    (void)mkdir(base.c_str(), 0700);
+  }
+  base += "/tsm_hip";
+  if (mkdir(base.c_str(), 0700) != 0 && errno != EEXIST) return "";
+  return base + "/tune_cache.txt";
 }
 
 bool tune_cache_load(tsm_engine *e, int key, std::vector<int> *codes) {
@@ -469,6 +492,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       if (want(name)) { tapped = true; return hit(y, nn, ho, wo, c3.cout); }
       return TSM_OK;
     }
+    const int r1 = e->zigzag ? (flip ^ 1) : 0;   // the walk direction conv() is about to give conv1 (kept for the tuner's A/B below)
     int rc1 = conv(blk.conv1, p1, 1, false);
     if (rc1) return rc1;
     if (want(name + ".conv1")) { tapped = true; return hit(t1, nn, hh, ww, c1.cout); }
@@ -509,6 +533,14 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       // discarded, best of the other three, and a sequence of launches timed back to back inside one event bracket (so
       // the inter-kernel boundaries and each kernel's cold start on its producer's output are priced, as in a forward).
       const int code1 = (*tiles)[blk.conv1], code2 = (*tiles)[blk.conv2], code3 = (*tiles)[blk.conv3];
+      // ... and with the tile walk directions of a forward (conv() sets `reverse` on its own copy only): separate launches
+      // alternate r1, !r1, r1; the fused conv2 + conv3 walks like conv2, the whole block like conv1 -- both arms of every
+      // comparison then see the producer / consumer cache reuse they would get in a real forward
+      p1.reverse = r1;
+      p2.reverse = e->zigzag ? (r1 ^ 1) : 0;
+      p3.reverse = r1;
+      pf.reverse = p2.reverse;
+      pb.reverse = r1;
       auto best_of = [&](auto &&launch, float *out_ms) -> int {
         float ms[4];
         for (int rep = 0; rep < 4; ++rep) {
@@ -561,6 +593,25 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   if (stage) return fail(e, TSM_ERR_INVALID_ARG, std::string("unknown stage: ") + stage);
   TSM_LAUNCH(e, s, tsm::launch_head(cur, e->d_fcw, e->d_fcb, e->d_pooled, d_logits, n_clips, T, h * w, 2048,
                                     cfg.num_class, prec, s));
+  return TSM_OK;
+}
+
+// The tile codes of the bucket `n_clips` falls into: already in memory, read from the tune cache file, or timed now on
+// the real launches over `d_clips` (synchronises; the codes then go to the cache file).
+int ensure_tuned(tsm_engine *e, const float *d_clips, int layout, int n_clips, float *d_out, hipStream_t s) {
+  const int tune_key = tile_bucket(n_clips) * e->cfg.num_segments;
+  if (!e->autotune || e->tile_cache.find(tune_key) != e->tile_cache.end()) return TSM_OK;
+  std::vector<int> cached(e->convs.size(), 0);
+  if (tune_cache_load(e, tune_key, &cached)) {
+    e->tile_cache.emplace(tune_key, cached);          // tuned by an earlier process (TSM_TUNE_CACHE)
+    return TSM_OK;
+  }
+  std::vector<hipEvent_t> *saved = e->cur_timing;
+  e->cur_timing = nullptr;
+  const int rc = run_forward(e, d_clips, layout, n_clips, d_out, s, nullptr, nullptr);
+  e->cur_timing = saved;
+  if (rc) return rc;
+  tune_cache_store(e, tune_key, e->tile_cache[tune_key]);
   return TSM_OK;
 }
 
@@ -637,10 +688,21 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (const char *f23 = getenv("TSM_FUSE_CONV23")) e->fuse23 = atoi(f23) != 0;
   if (const char *fb = getenv("TSM_FUSE_BLOCK")) e->fuse_block = atoi(fb) != 0;
   if (const char *zz = getenv("TSM_ZIGZAG")) e->zigzag = atoi(zz) != 0;
-  if (const char *tc = getenv("TSM_TUNE_CACHE")) {
+  // TSM_TUNE_CACHE=<file> names the tune cache; unset: a per-user default ($XDG_CACHE_HOME or $HOME/.cache, then
+  // tsm_hip/tune_cache.txt), so that the second process on a machine pays no tuning pass; "", "0" or "off" disables it.
+  {
+    const char *tc = getenv("TSM_TUNE_CACHE");
+    if (tc) {
+      if (*tc && strcmp(tc, "0") != 0 && strcmp(tc, "off") != 0) e->tune_path = tc;
+    } else {
+      e->tune_path = default_tune_cache_path();
+    }
+  }
+  if (!e->tune_path.empty()) {
     hipDeviceProp_t prop;
-    e->tune_path = tc;
-    e->tune_sig = "abi" + std::to_string(TSM_ABI_VERSION) + " " +
+    // (the build id: codes of another build of the library are still SAFE -- every code is validated against its layer at
+    //  launch -- but they were timed on other kernels, so they are not reused)
+    e->tune_sig = "abi" + std::to_string(TSM_ABI_VERSION) + " build " TSM_BUILD_ID " " +
                   (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess ? std::string(prop.gcnArchName) : "?") +
                   " T" + std::to_string(cfg->num_segments) + " " + std::to_string(cfg->height) + "x" +
                   std::to_string(cfg->width) + " dtype" + std::to_string(cfg->dtype) + " shift" +
@@ -840,20 +902,8 @@ int tsm_forward(tsm_engine *e, const void *clips, int32_t memkind, int32_t layou
   }
   // A forward that still has to tune its tile shapes does so in a throw-away pass first (it uses the
   // timing events and synchronises); the real pass below then runs from the cache.
-  const int tune_key = tile_bucket(n_clips) * e->cfg.num_segments;
-  if (e->autotune && e->tile_cache.find(tune_key) == e->tile_cache.end()) {
-    std::vector<int> cached(e->convs.size(), 0);
-    if (tune_cache_load(e, tune_key, &cached)) {
-      e->tile_cache.emplace(tune_key, cached);          // tuned by an earlier process (TSM_TUNE_CACHE)
-    } else {
-      std::vector<hipEvent_t> *saved = e->cur_timing;
-      e->cur_timing = nullptr;
-      rc = run_forward(e, d_clips, layout, n_clips, d_out, s, nullptr, nullptr);
-      e->cur_timing = saved;
-      if (rc) return rc;
-      tune_cache_store(e, tune_key, e->tile_cache[tune_key]);
-    }
-  }
+  rc = ensure_tuned(e, d_clips, layout, n_clips, d_out, s);
+  if (rc) return rc;
   TSM_HIP(e, hipEventRecord(e->ev0, s));
   rc = run_forward(e, d_clips, layout, n_clips, d_out, s, nullptr, nullptr);
   e->cur_timing = nullptr;
@@ -866,6 +916,24 @@ int tsm_forward(tsm_engine *e, const void *clips, int32_t memkind, int32_t layou
     TSM_HIP(e, hipStreamSynchronize(s));
   }
   return TSM_OK;
+}
+
+int tsm_tune(tsm_engine *e, int32_t n_clips, void *stream) {
+  if (!e) return TSM_ERR_INVALID_ARG;
+  if (!e->finalized) return fail(e, TSM_ERR_NOT_FINALIZED, "tsm_finalize has not been called");
+  if (n_clips <= 0) return fail(e, TSM_ERR_INVALID_ARG, "n_clips must be positive");
+  if (n_clips > e->cfg.max_clips)
+    return fail(e, TSM_ERR_CAPACITY, "n_clips " + std::to_string(n_clips) + " exceeds max_clips " + std::to_string(e->cfg.max_clips));
+  const int tune_key = tile_bucket(n_clips) * e->cfg.num_segments;
+  if (!e->autotune || e->tile_cache.find(tune_key) != e->tile_cache.end()) return TSM_OK;
+  TSM_HIP(e, hipSetDevice(e->cfg.device_id));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // the engine's own packed-input buffer, zeroed, stands in for a batch: no caller memory, no host copy, no kernel of
+  // anybody else's (a cold process pays first-use code-object loads for those)
+  const size_t frames = (size_t)n_clips * e->cfg.num_segments;
+  TSM_HIP(e, hipMemsetAsync(e->d_in4, 0, frames * 4 * e->cfg.height * (e->cfg.width + 1) * sizeof(float), s));
+  const int layout = e->prec == tsm::kPrecF32 ? TSM_LAYOUT_NTHWC4 : e->prec == tsm::kPrecBf16x3 ? TSM_LAYOUT_NTHWC8S : TSM_LAYOUT_NTHWC8B;
+  return ensure_tuned(e, e->d_in4, layout, n_clips, e->d_logits, s);
 }
 
 int tsm_forward_tap(tsm_engine *e, const void *clips, int32_t memkind, int32_t layout, int32_t n_clips,

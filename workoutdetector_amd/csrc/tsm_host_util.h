@@ -60,7 +60,7 @@ inline void to_split(std::vector<float> *v) {
   }
 }
 
-// Stem weights for the bf16 formats, whose input is stored as pixel pairs (tsm_kernels.hip, pack_input_kernel):
+// Stem weights for the bf16 formats, whose input is stored as pixel pairs (tsm_ops.hip, pack_input_kernel):
 // K = (ky, pair j, pixel-in-pair q, c4) = 7 x 4 x 2 x 4 = 224, covering pixels 2ox-4 .. 2ox+3, i.e. kx = 2j + q - 1
 // (kx = -1 and c = 3 carry zero weights).
 inline void fold_and_pack_stem_pairs(const float *w, const float *gamma, const float *beta, const float *mean,

@@ -1,4 +1,4 @@
-// Internal launch API shared by tsm_kernels.hip (device code) and tsm_engine.hip (host engine).
+// Internal launch API shared by the kernel files (csrc/tsm_*.hip, device code; tsm_device.h lists them) and tsm_engine.hip (host engine).
 // gfx950 only.  All activations NHWC fp32; weights packed [Cout][Kp] with K = (ky, kx, c).
 #pragma once
 #include <hip/hip_runtime.h>

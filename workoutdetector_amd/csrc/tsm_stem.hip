@@ -1,0 +1,524 @@
+// The 7x7 stride-2 stem as a direct convolution, with the 3x3 max-pool fused behind it.
+#include "tsm_device.h"
+
+namespace tsm {
+
+// ---------------------------------------------------------------------------------------------
+// stem_direct: the 7x7 stride-2 stem of the bf16 formats as a direct convolution from an LDS-resident input patch.
+// The generic implicit-GEMM loader gathers 28 groups of 8 elements per output pixel from L2 (each input pixel pair
+// is fetched ~12 times): with 3 input channels that gather, not the MFMA or HBM, bounds the stem in these formats.
+// Here a persistent workgroup keeps the packed weights [64][224] in LDS and, per (2 * WAVES) x 16 tile of output
+// pixels, loads the (4 * WAVES + 5) x 19 pixel-pair patch it needs ONCE (prefetched into registers under the previous
+// tile), then builds every MFMA A fragment straight from that patch: with K ordered (ky, pair j, pixel-in-pair, c4) a
+// fragment (8 consecutive k) is exactly one group of the patch at row 2*oy + ky, pair ox + j.  14 k16-steps x 2
+// N-tiles per wave and tile, no barrier inside.  Same products in the same order per accumulator as conv_igemm's
+// stem (whose trailing all-zero K padding is skipped), so results are bit-identical to it.
+// ---------------------------------------------------------------------------------------------
+constexpr int kStemTW = 16, kStemPC = kStemTW + 3;  // output tile width; input patch width in pixel pairs (19)
+
+// X3 = false: TSM_DTYPE_BF16 (16-byte groups of 8 bf16);  true: split-bf16 (32-byte groups [hi x8 | lo x8], three
+// MFMAs per product in conv_igemm's order ah*bh, ah*bl, al*bh).
+// WAVES waves per workgroup, each owning 2 rows x 16 columns of the (2 * WAVES) x 16 output tile: 4 for bf16 (75 KB of
+// LDS, two workgroups per CU), 8 for split-bf16 (one 159-KB workgroup per CU, two waves per SIMD).
+template <bool X3, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) stem_direct_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, float *__restrict__ y, int n,
+                                                          int hi, int wi, int ho, int wo, int kp, int relu) {
+  constexpr int NT = 64 * WAVES, kStemTH = 2 * WAVES, kStemPR = 2 * kStemTH + 5;  // threads; tile rows; patch rows
+  constexpr int GB = X3 ? 32 : 16;                    // bytes per 8-element group
+  // weight row stride in LDS: 28 groups + padding so that the rows of a 16-lane ds_read_b128 group fall on
+  // distinct 4-bank slots (stride in dwords = 4 mod 64)
+  constexpr int WROW = X3 ? 1040 : 528;
+  constexpr int OPX = X3 ? 256 : 128;                 // output bytes per pixel (64 channels)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * WROW + kStemPR * kStemPC * GB + 32 * WAVES * 68 * 4];
+  unsigned char *Ws = smem;
+  unsigned char *Ps = smem + 64 * WROW;
+  float *Cs = reinterpret_cast<float *>(smem + 64 * WROW + kStemPR * kStemPC * GB);  // [32 * WAVES][68] fp32 staging
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wpairs = (wi + 1) >> 1;
+
+  // weights -> LDS once per workgroup (64 rows x 28 groups)
+  constexpr int WCH = 28 * GB / 16;  // 16-byte chunks per row
+  for (int c = tid; c < 64 * WCH; c += NT) {
+    const int row = c / WCH, ch = c - row * WCH;
+    *reinterpret_cast<u32x4 *>(Ws + row * WROW + ch * 16) = *reinterpret_cast<const u32x4 *>(
+        reinterpret_cast<const unsigned char *>(w) + (size_t)row * kp * (GB / 8) + ch * 16);
+  }
+  const unsigned x_frame = (unsigned)hi * wpairs * GB, y_frame = (unsigned)ho * wo * OPX;  // bytes per frame
+  const float floor_ = relu ? 0.f : -INFINITY;
+
+  const int tiles_x = (wo + kStemTW - 1) / kStemTW, tiles_y = (ho + kStemTH - 1) / kStemTH;
+  const long n_tiles = (long)n * tiles_y * tiles_x;
+  // this lane's pixel inside the wave's 2 x 16 slice of the tile, and its A-fragment base inside the patch
+  const int pr = 2 * wave + (l31 >> 4), pc = l31 & 15;
+  const unsigned char *a_base = Ps + ((2 * pr) * kStemPC + pc) * GB;
+  const unsigned char *b_base = Ws + l31 * WROW;
+
+  // The patch of tile t+1 is fetched into registers while tile t is multiplied and stored (its global-load
+  // latency would otherwise be exposed once per tile: there is no K loop to hide it under).
+  constexpr int PCH = kStemPR * kStemPC * GB / 16;   // 16-byte chunks of a patch
+  constexpr int PPASS = (PCH + NT - 1) / NT;
+  u32x4 pre[PPASS];
+  auto fetch_patch = [&](long t) {
+    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+    const int iy0 = 2 * ty * kStemTH - 3, pc0 = tx * kStemTW - 2;
+    // descriptor rebased to the tile's frame: 32-bit offsets suffice whatever the batch
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(x) + (size_t)f * x_frame), 0, (int)x_frame, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q) {
+      const int ci = tid + q * NT;               // chunk index inside the patch
+      const int g = X3 ? ci >> 1 : ci;           // group index
+      const int r = g / kStemPC, c = g - r * kStemPC;
+      const int iy = iy0 + r, pcx = pc0 + c;
+      const bool ok = ci < PCH && (unsigned)iy < (unsigned)hi && (unsigned)pcx < (unsigned)wpairs;
+      const unsigned off = (unsigned)((iy * wpairs + pcx) * GB + (X3 ? (ci & 1) * 16 : 0));
+      pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)(ok ? off : kInvalid), 0, 0);
+    }
+  };
+  if ((long)blockIdx.x < n_tiles) fetch_patch(blockIdx.x);
+  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+    const int oy0 = ty * kStemTH, ox0 = tx * kStemTW;
+    const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(y) + (size_t)f * y_frame, 0, (int)y_frame, 0x00020000);
+    __syncthreads();  // previous tile's patch and staging are free (and the weights are in place)
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q)
+      if (tid + q * NT < PCH) *reinterpret_cast<u32x4 *>(Ps + (tid + q * NT) * 16) = pre[q];
+    if (t + gridDim.x < n_tiles) fetch_patch(t + gridDim.x);
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int s16 = 0; s16 < 14; ++s16) {
+      const int g = 2 * s16 + half;           // 8-element K group: (ky, pair j) = (g / 4, g % 4)
+      const unsigned char *ap = a_base + ((g >> 2) * kStemPC + (g & 3)) * GB;
+      const unsigned char *bp = b_base + g * GB;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap));
+      const bf16x8 bh0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp));
+      const bf16x8 bh1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 32 * WROW));
+      if constexpr (X3) {
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + 16));
+        const bf16x8 bl0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 16));
+        const bf16x8 bl1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 32 * WROW + 16));
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc[1], 0, 0, 0);
+      } else {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[1], 0, 0, 0);
+      }
+    }
+    // C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * half  ->  staging [pixel][channel]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        Cs[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * 68 + j * 32 + l31] = acc[j][e];
+    __syncthreads();
+    // 32 * WAVES pixels x 64 channels: thread -> (pixel tid / 2, 32 channels = 4 groups of 8)
+    {
+      const int px = tid >> 1, c0 = (tid & 1) * 32;
+      const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+      const bool ok = oy < ho && ox < wo;
+      const unsigned base = ok ? (unsigned)((oy * wo + ox) * OPX + (c0 / 8) * GB) : kInvalid;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(Cs + px * 68 + c0 + q * 8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4 *>(Cs + px * 68 + c0 + q * 8 + 4);
+        const f32x4 bb0 = *reinterpret_cast<const f32x4 *>(bias + c0 + q * 8);
+        const f32x4 bb1 = *reinterpret_cast<const f32x4 *>(bias + c0 + q * 8 + 4);
+        const float v[8] = {fmaxf(v0[0] + bb0[0], floor_), fmaxf(v0[1] + bb0[1], floor_), fmaxf(v0[2] + bb0[2], floor_),
+                            fmaxf(v0[3] + bb0[3], floor_), fmaxf(v1[0] + bb1[0], floor_), fmaxf(v1[1] + bb1[1], floor_),
+                            fmaxf(v1[2] + bb1[2], floor_), fmaxf(v1[3] + bb1[3], floor_)};
+        if constexpr (X3) {
+          u32x4 oh, ol;
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd) {
+            unsigned hw, lw;
+            split_pair(v[2 * wd], v[2 * wd + 1], &hw, &lw);
+            oh[wd] = hw;
+            ol[wd] = lw;
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(oh, rsrcY, (int)(ok ? base + q * 32 : kInvalid), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(ol, rsrcY, (int)(ok ? base + q * 32 + 16 : kInvalid), 0, 0);
+        } else {
+          u32x4 o;
+#pragma unroll
+          for (int wd = 0; wd < 4; ++wd) o[wd] = pack_bf16(v[2 * wd], v[2 * wd + 1]);
+          __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(ok ? base + q * 16 : kInvalid), 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem_pool: stem_direct with the 3x3 stride-2 max-pool fused behind it (bf16 formats).  A workgroup of 8 waves owns
+// a 7 x 8 tile of POOLED pixels = the 15 x 17 conv outputs under it (255 of its 256 MFMA rows; 14 % more conv work
+// than the 224 an un-pooled tiling would spend) and the 35 x 20 pixel-pair input patch under those.  The conv tile
+// is staged in LDS as fp32 after bias / ReLU and the format's rounding (so that the maximum is taken over exactly the
+// values the separate max-pool kernel would read back), conv pixels outside the image are -inf, and 448 threads
+// reduce one 8-channel group of one pooled pixel each.  The stem's 112 x 112 x 64 output (the largest tensor of the
+// network) is never written or re-read.  Bit-identical to stem_direct + maxpool3x3s2.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPoolPH = 7, kPoolPW = 8;                              // pooled tile
+constexpr int kPoolCR = 2 * kPoolPH + 1, kPoolCC = 2 * kPoolPW + 1;  // conv tile 15 x 17
+constexpr int kPoolPR = 2 * kPoolCR + 5, kPoolPC = kPoolCC + 3;      // input patch 35 rows x 20 pixel pairs
+
+template <bool X3>
+// (bf16: 77 760 B of LDS and <= 128 registers, so that TWO workgroups share a CU and overlap each other's phases)
+__global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                        const float *__restrict__ bias, float *__restrict__ y, int n,
+                                                        int hi, int wi, int ho, int wo, int hp, int wp, int kp, int relu) {
+  constexpr int NT = 512;
+  constexpr int GB = X3 ? 32 : 16;
+  constexpr int WROW = X3 ? 1040 : 464;   // weight row stride: data + padding, conflict-free ds_read_b128 over 16 rows
+  constexpr int CSB = X3 ? 256 * 68 * 4 : 256 * 72 * 2;   // the conv tile: [256][68] fp32, or (bf16) [256][72] bf16 bit patterns
+  constexpr int OPX = X3 ? 256 : 128;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * WROW + kPoolPR * kPoolPC * GB + CSB];
+  unsigned char *Ws = smem;
+  unsigned char *Ps = smem + 64 * WROW;
+  float *Cs = reinterpret_cast<float *>(smem + 64 * WROW + kPoolPR * kPoolPC * GB);  // X3: [256][68] fp32
+  unsigned short *Cs16 = reinterpret_cast<unsigned short *>(Cs);                     // bf16: [256][72] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wpairs = (wi + 1) >> 1;
+
+  constexpr int WCH = 28 * GB / 16;
+  for (int c = tid; c < 64 * WCH; c += NT) {
+    const int row = c / WCH, ch = c - row * WCH;
+    *reinterpret_cast<u32x4 *>(Ws + row * WROW + ch * 16) = *reinterpret_cast<const u32x4 *>(
+        reinterpret_cast<const unsigned char *>(w) + (size_t)row * kp * (GB / 8) + ch * 16);
+  }
+  const unsigned x_frame = (unsigned)hi * wpairs * GB, y_frame = (unsigned)hp * wp * OPX;
+  const float floor_ = relu ? 0.f : -INFINITY;
+  const int tiles_x = (wp + kPoolPW - 1) / kPoolPW, tiles_y = (hp + kPoolPH - 1) / kPoolPH;
+  const int tiles_f = tiles_x * tiles_y;
+  const int n_tiles = n * tiles_f;                 // (< 2^31: checked by the launcher)
+
+  // MFMA row i of the workgroup = conv pixel (i / 17, i % 17) of the tile; row 255 repeats the last pixel
+  const int mi = wave * 32 + l31;
+  const int mr = (mi < kPoolCR * kPoolCC ? mi : kPoolCR * kPoolCC - 1) / kPoolCC;
+  const int mc = (mi < kPoolCR * kPoolCC ? mi : kPoolCR * kPoolCC - 1) - mr * kPoolCC;
+  const unsigned char *a_base = Ps + ((2 * mr) * kPoolPC + mc) * GB;
+  const unsigned char *b_base = Ws + l31 * WROW;
+
+  constexpr int PCH = kPoolPR * kPoolPC * GB / 16;
+  constexpr int PPASS = (PCH + NT - 1) / NT;
+  u32x4 pre[PPASS];
+  auto fetch_patch = [&](int t) {
+    const int f = t / tiles_f, rem = t - f * tiles_f, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    // conv tile origin (2*py0 - 1, 2*px0 - 1)  ->  input rows from 2*(2*py0 - 1) - 3, pairs from (2*px0 - 1) - 2
+    const int iy0 = 4 * ty * kPoolPH - 5, pc0 = 2 * tx * kPoolPW - 3;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(x) + (size_t)f * x_frame), 0, (int)x_frame, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q) {
+      const int ci = tid + q * NT;
+      const int g = X3 ? ci >> 1 : ci;
+      const int r = g / kPoolPC, c = g - r * kPoolPC;
+      const int iy = iy0 + r, pcx = pc0 + c;
+      const bool ok = ci < PCH && (unsigned)iy < (unsigned)hi && (unsigned)pcx < (unsigned)wpairs;
+      const unsigned off = (unsigned)((iy * wpairs + pcx) * GB + (X3 ? (ci & 1) * 16 : 0));
+      pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)(ok ? off : kInvalid), 0, 0);
+    }
+  };
+  if ((int)blockIdx.x < n_tiles) fetch_patch((int)blockIdx.x);
+  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int f = t / tiles_f, rem = t - f * tiles_f, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int py0 = ty * kPoolPH, px0 = tx * kPoolPW;
+    const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;   // conv pixel of tile position (0, 0)
+    const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(y) + (size_t)f * y_frame, 0, (int)y_frame, 0x00020000);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q)
+      if (tid + q * NT < PCH) *reinterpret_cast<u32x4 *>(Ps + (tid + q * NT) * 16) = pre[q];
+    if (t + gridDim.x < n_tiles) fetch_patch(t + gridDim.x);
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int s16 = 0; s16 < 14; ++s16) {
+      const int g = 2 * s16 + half;
+      const unsigned char *ap = a_base + ((g >> 2) * kPoolPC + (g & 3)) * GB;
+      const unsigned char *bp = b_base + g * GB;
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap));
+      const bf16x8 bh0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp));
+      const bf16x8 bh1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 32 * WROW));
+      if constexpr (X3) {
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + 16));
+        const bf16x8 bl0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 16));
+        const bf16x8 bl1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 32 * WROW + 16));
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc[0], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc[1], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc[1], 0, 0, 0);
+      } else {
+        // bf16: the product TRANSPOSED (A = weights, B = pixels; the same products in the same order per accumulator):
+        // a lane then owns ONE conv pixel and 4-channel groups, which makes the epilogue below cheap (the stem is bound
+        // by its vector-ALU instruction count: 376 per wave and tile against 28 MFMAs before this, PMC)
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh0, ah, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh1, ah, acc[1], 0, 0, 0);
+      }
+    }
+    // conv tile -> LDS as the values the format would hold: bias, ReLU, round (bf16) or split + re-sum (split-bf16);
+    // conv pixels outside the image become -inf so that they never win the maximum (max-pool padding)
+    if constexpr (X3) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float bcol = bias[j * 32 + l31];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+          const int r = row / kPoolCC, c = row - r * kPoolCC;
+          const bool inside = row < kPoolCR * kPoolCC && (unsigned)(oy0 + r) < (unsigned)ho && (unsigned)(ox0 + c) < (unsigned)wo;
+          float v = fmaxf(acc[j][e] + bcol, floor_);
+          unsigned hw, lw;
+          split_pair(v, 0.f, &hw, &lw);
+          v = __builtin_bit_cast(float, hw << 16) + __builtin_bit_cast(float, lw << 16);
+          Cs[row * 68 + j * 32 + l31] = inside ? v : -INFINITY;
+        }
+      }
+    } else {
+      // lane = conv pixel mi (one inside-test), acc[j][4 q + i] = channel 32 j + 8 q + 4 half + i: four bf16 bit patterns
+      // (0xFF80 = -inf) per 8-byte LDS write
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const bool inside = mi < kPoolCR * kPoolCC && (unsigned)(oy0 + mr) < (unsigned)ho && (unsigned)(ox0 + mc) < (unsigned)wo;
+      const u32x2 ninf = {0xFF80FF80u, 0xFF80FF80u};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b = *reinterpret_cast<const f32x4 *>(bias + j * 32 + 8 * q + 4 * half);
+          u32x2 o;
+          o[0] = pack_bf16(fmaxf(acc[j][4 * q] + b[0], floor_), fmaxf(acc[j][4 * q + 1] + b[1], floor_));
+          o[1] = pack_bf16(fmaxf(acc[j][4 * q + 2] + b[2], floor_), fmaxf(acc[j][4 * q + 3] + b[3], floor_));
+          *reinterpret_cast<u32x2 *>(Cs16 + mi * 72 + j * 32 + 8 * q + 4 * half) = inside ? o : ninf;
+        }
+    }
+    __syncthreads();
+    if (tid < kPoolPH * kPoolPW * 8) {  // one 8-channel group of one pooled pixel per thread
+      const int pp = tid >> 3, cg = tid & 7;
+      const int pyl = pp / kPoolPW, pxl = pp - pyl * kPoolPW;
+      float m[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          f32x4 v0, v1;
+          if constexpr (X3) {
+            const float *src = Cs + ((2 * pyl + ky) * kPoolCC + 2 * pxl + kx) * 68 + cg * 8;
+            v0 = *reinterpret_cast<const f32x4 *>(src);
+            v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+          } else {
+            const u32x4 pkd = *reinterpret_cast<const u32x4 *>(Cs16 + ((2 * pyl + ky) * kPoolCC + 2 * pxl + kx) * 72 + cg * 8);
+            v0 = f32x4{__builtin_bit_cast(float, pkd[0] << 16), __builtin_bit_cast(float, pkd[0] & 0xFFFF0000u),
+                       __builtin_bit_cast(float, pkd[1] << 16), __builtin_bit_cast(float, pkd[1] & 0xFFFF0000u)};
+            v1 = f32x4{__builtin_bit_cast(float, pkd[2] << 16), __builtin_bit_cast(float, pkd[2] & 0xFFFF0000u),
+                       __builtin_bit_cast(float, pkd[3] << 16), __builtin_bit_cast(float, pkd[3] & 0xFFFF0000u)};
+          }
+          m[0] = fmaxf(m[0], v0[0]); m[1] = fmaxf(m[1], v0[1]); m[2] = fmaxf(m[2], v0[2]); m[3] = fmaxf(m[3], v0[3]);
+          m[4] = fmaxf(m[4], v1[0]); m[5] = fmaxf(m[5], v1[1]); m[6] = fmaxf(m[6], v1[2]); m[7] = fmaxf(m[7], v1[3]);
+        }
+      const int py = py0 + pyl, px = px0 + pxl;
+      const bool ok = py < hp && px < wp;
+      const unsigned base = ok ? (unsigned)((py * wp + px) * OPX + cg * GB) : kInvalid;
+      if constexpr (X3) {
+        u32x4 oh, ol;
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+          unsigned hw, lw;
+          split_pair(m[2 * wd], m[2 * wd + 1], &hw, &lw);
+          oh[wd] = hw;
+          ol[wd] = lw;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(oh, rsrcY, (int)base, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(ol, rsrcY, (int)(ok ? base + 16 : kInvalid), 0, 0);
+      } else {
+        u32x4 o;
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) o[wd] = pack_bf16(m[2 * wd], m[2 * wd + 1]);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)base, 0, 0);
+      }
+    }
+  }
+}
+
+// fp32 form of stem_pool.  Input NHWC4 (one 16-byte group per pixel), weights [64][Kp] fp32 with K = (ky, kx, c4);
+// the conv tile's patch is 35 rows x 39 pixels.  MFMA sequence = conv_igemm's fp32 stem exactly: v_mfma_f32_32x32x2_f32
+// sums k = {4 * tap + s of lane-half 0, of lane-half 1}, taps taken in pairs (2g, 2g + 1), s = 0..3, g = 0..24, so
+// the results are bit-identical to it (tap 49 is K padding: zero weights, its A operand re-reads tap 48).
+constexpr int kPoolPCF = 2 * (kPoolCC - 1) + 7;   // 39 input pixels per patch row
+
+__global__ void __launch_bounds__(512) stem_pool_f32_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ y, int n,
+                                                            int hi, int wi, int ho, int wo, int hp, int wp, int kp,
+                                                            int relu) {
+  constexpr int NT = 512;
+  constexpr int WROW = 1040;                      // 200 used floats + padding: row stride = 4 dwords mod 64
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * WROW + kPoolPR * kPoolPCF * 16 + 256 * 68 * 4];
+  unsigned char *Ws = smem;
+  unsigned char *Ps = smem + 64 * WROW;
+  float *Cs = reinterpret_cast<float *>(smem + 64 * WROW + kPoolPR * kPoolPCF * 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  for (int c = tid; c < 64 * 50; c += NT) {       // 50 chunks of 16 B = taps 0..49 (tap 49 = zero padding)
+    const int row = c / 50, ch = c - row * 50;
+    *reinterpret_cast<f32x4 *>(Ws + row * WROW + ch * 16) = *reinterpret_cast<const f32x4 *>(w + (size_t)row * kp + ch * 4);
+  }
+  const unsigned x_frame = (unsigned)hi * wi * 16, y_frame = (unsigned)hp * wp * 256;
+  const float floor_ = relu ? 0.f : -INFINITY;
+  const int tiles_x = (wp + kPoolPW - 1) / kPoolPW, tiles_y = (hp + kPoolPH - 1) / kPoolPH;
+  const long n_tiles = (long)n * tiles_y * tiles_x;
+
+  const int mi = wave * 32 + l31;
+  const int mr = (mi < kPoolCR * kPoolCC ? mi : kPoolCR * kPoolCC - 1) / kPoolCC;
+  const int mc = (mi < kPoolCR * kPoolCC ? mi : kPoolCR * kPoolCC - 1) - mr * kPoolCC;
+  const unsigned char *a_base = Ps + ((2 * mr) * kPoolPCF + 2 * mc) * 16;
+  const unsigned char *b_base = Ws + l31 * WROW;
+
+  constexpr int PCH = kPoolPR * kPoolPCF;
+  constexpr int PPASS = (PCH + NT - 1) / NT;
+  u32x4 pre[PPASS];
+  auto fetch_patch = [&](long t) {
+    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+    const int iy0 = 4 * ty * kPoolPH - 5, ix0 = 4 * tx * kPoolPW - 5;   // 2 * (2 * p0 - 1) - 3
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(x) + (size_t)f * x_frame), 0, (int)x_frame, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q) {
+      const int ci = tid + q * NT;
+      const int r = ci / kPoolPCF, c = ci - r * kPoolPCF;
+      const int iy = iy0 + r, ix = ix0 + c;
+      const bool ok = ci < PCH && (unsigned)iy < (unsigned)hi && (unsigned)ix < (unsigned)wi;
+      pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)(ok ? (unsigned)((iy * wi + ix) * 16) : kInvalid), 0, 0);
+    }
+  };
+  if ((long)blockIdx.x < n_tiles) fetch_patch(blockIdx.x);
+  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
+    const int py0 = ty * kPoolPH, px0 = tx * kPoolPW;
+    const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;
+    const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(y) + (size_t)f * y_frame, 0, (int)y_frame, 0x00020000);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PPASS; ++q)
+      if (tid + q * NT < PCH) *reinterpret_cast<u32x4 *>(Ps + (tid + q * NT) * 16) = pre[q];
+    if (t + gridDim.x < n_tiles) fetch_patch(t + gridDim.x);
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 25; ++g) {
+      const int tap = 2 * g + half;                       // 0..49; 49 is K padding (zero weights)
+      const int tapa = tap < 49 ? tap : 48;               // its A operand must still be a finite number
+      const int ky = tapa / 7, kx = tapa - ky * 7;
+      const f32x4 a = *reinterpret_cast<const f32x4 *>(a_base + (ky * kPoolPCF + kx) * 16);
+      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(b_base + tap * 16);
+      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(b_base + 32 * WROW + tap * 16);
+      // Channels 0..2 only.  The generic kernel also multiplies the packed input's fourth channel -- +0 in the input
+      // (pack_input / tsm_preprocess write it) times +0 in the packed weights -- which leaves every accumulator bit as it
+      // is: an fp32 accumulator that starts at +0 is never -0 under round-to-nearest (x + (-x) and (+0) + (-0) are +0),
+      // so acc + (+0) == acc.  A quarter of the stem's MFMAs were those (K = 49 taps x 4 -> x 3: 200 -> 150 per tile).
+#pragma unroll
+      for (int s4 = 0; s4 < 3; ++s4) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b0[s4], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b1[s4], acc[1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float bcol = bias[j * 32 + l31];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int r = row / kPoolCC, c = row - r * kPoolCC;
+        const bool inside = row < kPoolCR * kPoolCC && (unsigned)(oy0 + r) < (unsigned)ho && (unsigned)(ox0 + c) < (unsigned)wo;
+        Cs[row * 68 + j * 32 + l31] = inside ? fmaxf(acc[j][e] + bcol, floor_) : -INFINITY;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                          // 56 pooled pixels x 16 channel quads = 896 items
+      const int item = tid + q * NT;
+      if (item < kPoolPH * kPoolPW * 16) {
+        const int pp = item >> 4, cq = item & 15;
+        const int pyl = pp / kPoolPW, pxl = pp - pyl * kPoolPW;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(Cs + ((2 * pyl + ky) * kPoolCC + 2 * pxl + kx) * 68 + cq * 4);
+            m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+          }
+        const int py = py0 + pyl, px = px0 + pxl;
+        const bool ok = py < hp && px < wp;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), rsrcY,
+                                               (int)(ok ? (unsigned)((py * wp + px) * 256 + cq * 16) : kInvalid), 0, 0);
+      }
+    }
+  }
+}
+
+hipError_t launch_stem_pool(const float *x, const float *w, const float *bias, float *y, int n, int hi, int wi, int kp,
+                            int relu, int prec, hipStream_t s) {
+  const int ho = (hi + 6 - 7) / 2 + 1, wo = (wi + 6 - 7) / 2 + 1;
+  const int hp = (ho + 2 - 3) / 2 + 1, wp = (wo + 2 - 3) / 2 + 1;
+  if (!x || !w || !bias || !y || n <= 0 || hi <= 0 || wi <= 0 || kp < 200) return hipErrorInvalidValue;
+  if (prec != kPrecBf16 && prec != kPrecBf16x3 && prec != kPrecF32) return hipErrorInvalidValue;
+  if ((double)hi * wi * 16.0 > 2.0e9 || (prec != kPrecF32 && kp < 224)) return hipErrorInvalidValue;
+  const long tiles = (long)n * ((hp + kPoolPH - 1) / kPoolPH) * ((wp + kPoolPW - 1) / kPoolPW);
+  if (tiles >= (1L << 31) - 1024) return hipErrorInvalidValue;
+  const long cap = (long)device_info().n_cu * (prec == kPrecBf16 ? 2 : 1);   // persistent: one 8-wave workgroup per CU (bf16: two)
+  const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+  if (prec == kPrecF32)
+    hipLaunchKernelGGL(stem_pool_f32_kernel, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
+  else if (prec == kPrecBf16)
+    hipLaunchKernelGGL(stem_pool_kernel<false>, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
+  else
+    hipLaunchKernelGGL(stem_pool_kernel<true>, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
+  return hipGetLastError();
+}
+
+hipError_t launch_stem_direct(const float *x, const float *w, const float *bias, float *y, int n, int hi, int wi, int kp,
+                              int relu, int prec, hipStream_t s) {
+  const int ho = (hi + 6 - 7) / 2 + 1, wo = (wi + 6 - 7) / 2 + 1;
+  if (!x || !w || !bias || !y || n <= 0 || hi <= 0 || wi <= 0 || kp < 224) return hipErrorInvalidValue;
+  if (prec != kPrecBf16 && prec != kPrecBf16x3) return hipErrorInvalidValue;
+  if ((double)hi * ((wi + 1) / 2) * 32.0 > 2.0e9 || (double)ho * wo * 256.0 > 2.0e9) return hipErrorInvalidValue;
+  const int th = prec == kPrecBf16 ? 8 : 16;
+  const long tiles = (long)n * ((ho + th - 1) / th) * ((wo + kStemTW - 1) / kStemTW);
+  // persistent workgroups: two per CU for bf16 (4 waves, 75 KB of LDS each), one per CU for split-bf16 (8 waves, 159 KB)
+  const long cap = (long)device_info().n_cu * (prec == kPrecBf16 ? 2 : 1);
+  const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+  if (prec == kPrecBf16)
+    hipLaunchKernelGGL((stem_direct_kernel<false, 4>), dim3(grid), dim3(256), 0, s, x, w, bias, y, n, hi, wi, ho, wo, kp, relu);
+  else
+    hipLaunchKernelGGL((stem_direct_kernel<true, 8>), dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, kp, relu);
+  return hipGetLastError();
+}
+
+}  // namespace tsm

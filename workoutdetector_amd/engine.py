@@ -181,8 +181,9 @@ class TsmEngine:
         return out
 
     def warmup(self, batch_sizes: Optional[Sequence[int]] = None) -> 'TsmEngine':
-        """Run one forward per power-of-two bucket of the clip count (default: 1, 2, 4, ... max_clips) so that the
-        per-bucket tile / split-K autotuning (a few hundred ms each) happens now and not on the first real request."""
+        """Tune every power-of-two bucket of the clip count that will occur (default: 1, 2, 4, ... max_clips) now
+        (``tsm_tune``: a few hundred ms each of timed launches on the engine's own zeroed input buffer, or nothing when
+        the tune cache file already holds the bucket), not inside the first real request."""
         import torch
         self._need_finalized()
         if batch_sizes is None:
@@ -191,11 +192,10 @@ class TsmEngine:
                 batch_sizes.append(b)
                 b *= 2
             batch_sizes.append(self.max_clips)
-        dev = torch.device('cuda', self.device)
+        stream = torch.cuda.current_stream(torch.device('cuda', self.device)).cuda_stream
         for b in batch_sizes:
             b = max(1, min(int(b), self.max_clips))
-            self.forward_device(torch.zeros((b, self.num_segments, 3, self.height, self.width), device=dev))
-        torch.cuda.synchronize(dev)
+            _lib.check(self._lib.tsm_tune(self._h, b, stream), self._h)
         return self
 
     def forward_tap(self, clips: np.ndarray, stage: str) -> np.ndarray:
