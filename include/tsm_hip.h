@@ -171,7 +171,9 @@ int tsm_layer_times(tsm_engine *e, int32_t forward_index, float *ms_out, int32_t
  * channels), 8 = the 256x256 kernel run persistently over a workgroup's tiles (bf16, K >= 128), 0 = not tuned (heuristic); + 256 = split-K form of a segmented fp32 layer (one workgroup per tile and K
  * segment, combined in segment order); + 1024 (on conv2's code) = the block runs conv2 + conv3 + residual as ONE launch
  * (conv3's slot is then not used); + 2048 (on conv1's code) = the WHOLE block -- shift, conv1, conv2, conv3 (+ the fused
- * downsample branch) + identity -- runs as ONE launch (bf16 layer1; the conv2 / conv3 slots are then not used).
+ * downsample branch) + identity -- runs as ONE launch (bf16 layer1; the conv2 / conv3 slots are then not used); + 4096 (on
+ * conv3's code) = that launch also runs the temporal shift + conv1 of the NEXT block (bf16 layer2; the next block's conv1
+ * slot is then not used).
  * The first tsm_forward with a new power-of-two bucket of n_clips
  * times every valid code per layer once, SYNCHRONOUSLY (see Conventions: not capture-safe, a few hundred ms; results are
  * bit-identical across codes); TSM_AUTOTUNE=0 in the environment at tsm_create disables it, TSM_TUNE_CACHE=<file> lets a

@@ -385,3 +385,59 @@ def test_whole_bottleneck_kernel_equals_the_separate_launches_bitwise(hip_lib, m
     for name, a, c in zip(('layer1.0', 'layer1.1', 'layer1.2', 'layer2.0', 'logits'), got['1'], got['0']):
         assert np.array_equal(a, c), name
     assert np.isfinite(got['1'][-1]).all()
+
+
+@pytest.mark.parametrize('h,w,b,t,div,shift', [
+    (256, 256, 2, 16, 8, True),    # the config-5 geometry: 32 x 32 frames at layer2, tiles of 16 frames x 16 pixels
+    (224, 224, 3, 8, 8, True),     # the headline geometry: 28 x 28 = 784 pixels, tiles of 8 x 32 (the 25th tile of a clip is half empty)
+    (96, 64, 5, 4, 8, True),       # 12 x 8 = 96 pixels, T = 4: tiles of 4 x 64, the second one half empty; more tiles than some workgroups' share
+    (90, 70, 3, 8, 8, True),       # 12 x 9 = 108 pixels: ragged in the last tile, odd row length
+    (64, 64, 3, 2, 8, True),       # T = 2: tiles of 2 x 128 pixels over 8 x 8 frames (one tile holds a whole clip)
+    (224, 224, 2, 8, 8, False),    # no temporal shift: every chunk reads its own rows
+    (128, 128, 2, 32, 8, True),    # T = 32: tiles of 32 frames x 8 pixels (a wave's rows are four frames of one pixel run)
+    (72, 40, 3, 3, 8, True),       # odd segment count: no clip-major tile exists -- the forced switch must fall back, same bits
+    (64, 96, 2, 64, 8, True),      # T = 64 > 32: not enough pixels per tile -- falls back as well
+])
+def test_conv3_conv1_cross_block_kernel_equals_the_separate_launches_bitwise(hip_lib, monkeypatch, h, w, b, t, div, shift):
+    """conv31_fused_kernel (conv3 + residual + ReLU of layer2.k and temporal shift + conv1 of layer2.k+1 as ONE
+    launch on clip-major tiles -- all T frames of a clip x 256 / T pixels, so the frames t +- 1 the shifted channels come
+    from are rows of the same tile; models/tsm.py:35-50,125-137 across the Bottleneck boundary) against the two launches it
+    replaces: every layer2 block output (= the kernel's y), the next block's conv1 tap (= its t1) and the logits, bit for
+    bit -- BASELINE geometries, ragged tiles, T from 2 to 32, no shift, and geometries without a clip-major tile."""
+    from workoutdetector_amd.engine import TsmEngine
+    from workoutdetector_amd.weights import make_state_dict
+    sd = make_state_dict(13, 12)
+    x = make_input(700 + h + t, b, t, h, w)
+    stages = ('layer2.0', 'layer2.1', 'layer2.2.conv1', 'layer2.2', 'layer2.3.conv1', 'layer2.3', 'layer3.0')
+    got = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('TSM_FUSE_C3C1', flag)
+        eng = TsmEngine(num_segments=t, height=h, width=w, shift_div=div, is_shift=shift, max_clips=b, state_dict=sd, dtype='bf16')
+        got[flag] = [eng.run(None, {'input': x})[0]] + [eng.forward_tap(x, s) for s in stages] + [eng.run(None, {'input': x})[0]]
+        eng.close()
+    for name, a, c in zip(('logits',) + stages + ('logits again',), got['1'], got['0']):
+        assert np.array_equal(a, c), name
+    assert np.isfinite(got['1'][0]).all() and np.array_equal(got['1'][0], got['1'][-1])
+
+
+def test_tuner_may_choose_the_cross_block_kernel_and_reports_it(hip_lib, sd0):
+    """At the config-5 geometry the tuner times conv3 + the next conv1 as one launch against the tuned pair (bit 4096 of
+    conv3's tile code, '+conv1' in conv_tiles); whatever it picks, the logits are those of an engine that may not fuse."""
+    import os
+    from workoutdetector_amd.engine import TsmEngine
+    x = make_input(77, 4, 16, 256, 256)
+    eng = TsmEngine(num_segments=16, height=256, width=256, max_clips=4, state_dict=sd0, dtype='bf16')
+    ya = eng.run(None, {'input': x})[0]
+    tiles = eng.conv_tiles(4)
+    eng.close()
+    fused = [k for k, v in tiles.items() if v.endswith('+conv1')]
+    assert all(k in ('layer2.1.conv3', 'layer2.2.conv3') for k in fused), fused
+    os.environ['TSM_FUSE_C3C1'] = '0'
+    try:
+        ref = TsmEngine(num_segments=16, height=256, width=256, max_clips=4, state_dict=sd0, dtype='bf16')
+        yb = ref.run(None, {'input': x})[0]
+        assert not any(v.endswith('+conv1') for v in ref.conv_tiles(4).values())
+        ref.close()
+    finally:
+        del os.environ['TSM_FUSE_C3C1']
+    assert np.array_equal(ya, yb)

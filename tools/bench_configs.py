@@ -198,9 +198,18 @@ def config4_scaling(args):
         if rank != 0:
             dist.barrier()       # rank 0 tunes first; the others read its choices (shared TSM_TUNE_CACHE)
     eng = TsmEngine(max_clips=32, state_dict=make_state_dict(0, 12), dtype=args.dtype, device=local_rank)
-    eng.warmup()
+    if not args.cold:
+        eng.warmup()             # (--cold: the job itself tunes / reads the tune cache while its first frames are staged)
     if world > 1 and rank == 0:
         dist.barrier()
+    first = {}
+    real_forward = eng.forward_device
+
+    def timed_forward(*a, **k):          # host time of the job's first forward launch (cold-job head)
+        first.setdefault('t', time.perf_counter())
+        return real_forward(*a, **k)
+
+    eng.forward_device = timed_forward
     import contextlib
     import io
     sync()
@@ -225,6 +234,8 @@ def config4_scaling(args):
             'value': None if rehearsal else round(sum(clips) / float(dt.item()), 2), 'unit': 'clips/s', 'n_gpus': world,
             'scaling': 'strong', 'dtype': args.dtype, 'videos': len(frames), 'clips': sum(clips),
             'job_s': round(float(dt.item()), 4), 'frame_size': args.frame_size, 'clips_per_rank': load,
+            'cold': bool(args.cold), 'tune_cache': os.environ.get('TSM_TUNE_CACHE', 'default (~/.cache/tsm_hip/tune_cache.txt)'),
+            'first_forward_after_s': round(first['t'] - t0, 4) if 't' in first else None,
             'plan_efficiency': round(tdist.shard_efficiency(clips, owner, world), 4),
             'lockstep_round_robin_efficiency': round(tdist.lockstep_efficiency(clips, world), 4),
             **({'rehearsal': True} if rehearsal else {}),
@@ -247,6 +258,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--videos', type=int, default=0, help='config 4: only the first N val videos (rehearsals)')
     ap.add_argument('--frame-size', default='360x206', help='config 4: HxW of the synthetic decoded frames')
+    ap.add_argument('--cold', action='store_true', help='config 4: no warmup() before the job (a cold process: the job tunes '
+                                                        'or reads the tune cache itself, under the staging of its first frames)')
     args = ap.parse_args()
     if args.config == 4:
         config4_scaling(args)

@@ -1,8 +1,345 @@
-// conv31_fused_kernel (placeholder until the kernel lands)
+// conv31_fused_kernel: Bottleneck.conv3 + bn3 + residual + ReLU of block b  AND  temporal shift + conv1 + bn1 + ReLU of
+// block b + 1 in ONE launch (bf16; layer2's non-first blocks).
 #include "tsm_device.h"
 
 namespace tsm {
 
-hipError_t opt_in_conv31() { return hipSuccess; }
+// ---------------------------------------------------------------------------------------------
+// Why: in the bf16 engine every launch of layer2 sits on its own roofline, so what is left are the bytes BETWEEN
+// launches: conv3 of block b writes the block output y (H*W*C*2 bytes per frame) and conv1 of block b + 1 reads all of it
+// back one launch later (1.07 GB per block at the config-5 size).  Fusing the two across the block boundary looked
+// forbidden -- conv1 reads its first C/8 channels from frame t + 1 and the next C/8 from frame t - 1 (models/tsm.py:35-50),
+// so a SPATIAL tile of y does not hold conv1's input.  A CLIP-MAJOR tile does: a tile here is ALL T frames of one clip x
+// PX consecutive pixels (T * PX = 256 rows, row = t * PX + px), and the shifted channels of row (t, px) are the same
+// channels of rows (t +- 1, px) of the SAME tile -- a row offset of +- PX inside the tile, zeros where t +- 1 leaves the clip.
+//
+// One persistent 8-wave workgroup per CU; wave w owns tile rows 32 w .. 32 w + 31 in both GEMMs.  Per tile:
+//   * t2 (conv3's input, [256][K3] bf16) arrives by LDS-DMA in a staging buffer a whole tile ahead and is read ONCE into
+//     registers as the A fragments of GEMM1 (K3 / 16 fragments per lane);
+//   * the block channels are walked in chunks of 64:  GEMM1  y[:, chunk] = t2 * W3[chunk, :]^T  (16 MFMAs per wave, B
+//     fragments from the chunk of W3 that LDS-DMA brought in during the previous chunk);  epilogue through a wave-private
+//     [8][68] fp32 sub-slab: + bias3, + residual (16 bytes per lane = whole 128-byte row segments per 8 lanes, loaded into
+//     registers one chunk ahead), ReLU, bf16 -> (a) stored to y (the next block's identity needs it: written once, never
+//     re-read by this kernel), (b) written to a [256][64] bf16 LDS tile;  GEMM2  t1 += shift(y[:, chunk]) * W1[:, chunk]^T
+//     (16 MFMAs per wave; the A fragments are rows r, r + PX or r - PX of the LDS tile according to the chunk's place in
+//     the channel order, a zero row past the clip's ends; the B fragments the chunk of W1 brought in by LDS-DMA);
+//   * after the last chunk: t1 = relu(acc + bias1) -> bf16 -> stored ([256][N1], conv2 of block b + 1 reads it).
+// HBM bytes per tile row: K3*2 (t2) + C*2 (residual) + C*2 (y) + N1*2 (t1) against + C*2 more for the two launches it
+// replaces; the weights (C*K3 + N1*C elements per tile) stream from L2.  Three barriers per chunk; every vector-memory
+// wait is a counted vmcnt over the fixed issue order of a chunk
+//     [W1 chunk: NW1 DMA | W3 next chunk: NW3 DMA | (store y, load next residual) x 4 | t2 of the next tile: P DMA],
+// never vmcnt(0) inside the loop: the residual stream, the weight stream and the next tile's t2 stay in flight under
+// both GEMMs and the epilogue.
+// Products enter every accumulator in the separate kernels' order (k16 groups ascending from a zero accumulator) and the
+// two epilogues are theirs (conv_bf16_256p's residual arm; its shifted-conv1 arm): bit-identical to the two launches.
+// Needs T | 256 with 8 <= 256 / T (all frames of a clip in one tile), fold % 64 == 0 (a chunk is shifted as a whole).
+// ---------------------------------------------------------------------------------------------
+template <int K3, int C, int N1> struct C31 {
+  static constexpr int M = 256;                    // tile rows = T frames x PX pixels
+  static constexpr int KT1 = K3 / 16;              // k16 steps of GEMM1
+  static constexpr int NC = C / 64;                // chunks of the block's channels
+  static constexpr int RB3 = K3 * 2;               // bytes per row of t2 / of W3
+  static constexpr int LPR3 = RB3 / 16;            // lanes (16-byte slots) per such row
+  static constexpr int RPP3 = 1024 / RB3;          // rows per 1-KiB DMA piece
+  static constexpr int NW3 = 64 * RB3 / 1024 / 8;  // DMA pieces per wave: a chunk of W3 (64 rows)
+  static constexpr int NW1 = N1 * 128 / 1024 / 8;  // ... a chunk of W1 (N1 rows x 64 channels)
+  static constexpr int NT2 = M * RB3 / 1024 / 8;   // ... the t2 tile
+  static constexpr int NT1S = 4 * (N1 / 64);       // t1 stores per wave and tile
+  static constexpr int LOG_C_N1 = C / N1 == 4 ? 2 : C / N1 == 2 ? 1 : 0;
+  static constexpr int kW3 = 0;
+  static constexpr int kW1 = kW3 + 64 * RB3;
+  static constexpr int kY = kW1 + N1 * 128;
+  static constexpr int kT2 = kY + M * 128;
+  static constexpr int kSlab = kT2 + M * RB3;
+  static constexpr int kBias3 = kSlab + 8 * 2176;
+  static constexpr int kBias1 = kBias3 + C * 4;
+  static constexpr int kZero = kBias1 + N1 * 4;
+  static constexpr int kBytes = kZero + 128;
+  static_assert(C / N1 == 4 || C / N1 == 2, "t1's row offsets are derived from y's by a shift");
+  static_assert(NT2 == 8 && NC >= 5, "the t2 pieces of the next tile ride on chunks 0-3, two per chunk");
+  static_assert(kBytes <= 160 * 1024, "LDS budget");
+};
+
+// t2 pieces of the NEXT tile issued in chunk nc (all in the first half of the tile, so that they have landed -- behind
+// waits this wave passes anyway -- long before the next tile's first GEMM needs them)
+__device__ __forceinline__ constexpr int c31_pieces(int nc) { return nc < 4 ? 2 : 0; }
+
+__device__ __forceinline__ void wait_vmcnt_any(int n) {
+#define TSM_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    TSM_VMCNT_CASE(0) TSM_VMCNT_CASE(1) TSM_VMCNT_CASE(2) TSM_VMCNT_CASE(3) TSM_VMCNT_CASE(4) TSM_VMCNT_CASE(5)
+    TSM_VMCNT_CASE(6) TSM_VMCNT_CASE(7) TSM_VMCNT_CASE(8) TSM_VMCNT_CASE(9) TSM_VMCNT_CASE(10) TSM_VMCNT_CASE(11)
+    TSM_VMCNT_CASE(12) TSM_VMCNT_CASE(13) TSM_VMCNT_CASE(14) TSM_VMCNT_CASE(15) TSM_VMCNT_CASE(16) TSM_VMCNT_CASE(17)
+    TSM_VMCNT_CASE(18) TSM_VMCNT_CASE(19) TSM_VMCNT_CASE(20) TSM_VMCNT_CASE(21) TSM_VMCNT_CASE(22) TSM_VMCNT_CASE(23)
+    TSM_VMCNT_CASE(24) TSM_VMCNT_CASE(25) TSM_VMCNT_CASE(26) TSM_VMCNT_CASE(27) TSM_VMCNT_CASE(28) TSM_VMCNT_CASE(29)
+    TSM_VMCNT_CASE(30) TSM_VMCNT_CASE(31) TSM_VMCNT_CASE(32)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef TSM_VMCNT_CASE
+}
+
+template <int K3, int C, int N1>
+__global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params p) {
+  typedef C31<K3, C, N1> L;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31, c8 = lane & 7, r8l = lane >> 3;
+  const int T = p.T, HW = p.HW;
+  const int lpx = p.log_px, PX = 1 << lpx;               // pixels of a tile: 256 / T
+  const int tpc = (HW + PX - 1) >> lpx;                   // tiles per clip
+  const int ntiles = p.n_clips * tpc, nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+  const int my = (ntiles - bid + nwg - 1) / nwg;          // tiles of this workgroup (>= 1: the grid never exceeds the tiles)
+
+  float *bias3_l = reinterpret_cast<float *>(lds + L::kBias3), *bias1_l = reinterpret_cast<float *>(lds + L::kBias1);
+  for (int i = tid; i < C; i += 512) bias3_l[i] = p.bias3[i];
+  for (int i = tid; i < N1; i += 512) bias1_l[i] = p.bias1[i];
+  if (tid < 32) reinterpret_cast<unsigned *>(lds + L::kZero)[tid] = 0u;
+
+  // ---- per-lane constants -------------------------------------------------------------------------------------
+  // epilogue: this lane's row of sub-slab q is tile row 32 wave + 8 q + r8l; it handles channels 8 c8 .. 8 c8 + 7 of a chunk
+  unsigned evoff[4], epx[4], yw[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = 32 * wave + 8 * q + r8l;
+    const int t = row >> lpx, px = row & (PX - 1);
+    evoff[q] = (unsigned)((t * HW + px) * (C * 2) + c8 * 16);          // byte offset in the clip's [T*HW][C] block (+ p0 * C * 2)
+    epx[q] = (unsigned)px;
+    yw[q] = (unsigned)(L::kY + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4));
+  }
+  // GEMM2's A fragments: tile row r = 32 wave + l31 as it stands, or rows r + PX / r - PX (frames t + 1 / t - 1), or zeros
+  unsigned ybase[3], yflip[3];
+  {
+    const int r = 32 * wave + l31, t = r >> lpx;
+    const int rp = r + PX, rm = r - PX;
+    ybase[0] = (unsigned)(L::kY + r * 128);   yflip[0] = (unsigned)((r >> 1) & 7);
+    ybase[1] = t + 1 < T ? (unsigned)(L::kY + rp * 128) : (unsigned)L::kZero;   yflip[1] = t + 1 < T ? (unsigned)((rp >> 1) & 7) : 0u;
+    ybase[2] = t > 0 ? (unsigned)(L::kY + rm * 128) : (unsigned)L::kZero;       yflip[2] = t > 0 ? (unsigned)((rm >> 1) & 7) : 0u;
+  }
+  const unsigned w1rd = (unsigned)(L::kW1 + l31 * 128), w1flip = (unsigned)((l31 >> 1) & 7);
+  const unsigned w3rd = (unsigned)(L::kW3 + l31 * L::RB3), rflip = (unsigned)(l31 & 15);
+  const unsigned t2rd = (unsigned)(L::kT2 + (32 * wave + l31) * L::RB3);
+  // DMA sources (the 16-byte chunk a lane fetches is swizzled on the SOURCE side; the LDS side is linear per piece)
+  unsigned w3off[L::NW3], w1off[L::NW1];
+#pragma unroll
+  for (int i = 0; i < L::NW3; ++i) {
+    const int row = (wave * L::NW3 + i) * L::RPP3 + lane / L::LPR3, slot = lane % L::LPR3;
+    w3off[i] = (unsigned)(row * L::RB3 + ((slot ^ (row & 15)) << 4));
+  }
+#pragma unroll
+  for (int i = 0; i < L::NW1; ++i) {
+    const int row = (wave * L::NW1 + i) * 8 + (lane >> 3), slot = lane & 7;
+    w1off[i] = (unsigned)(row * (C * 2) + ((slot ^ ((row >> 1) & 7)) << 4));
+  }
+  const __amdgpu_buffer_rsrc_t rsrcW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w3), 0, C * K3 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w1), 0, N1 * C * 2, 0x00020000);
+  const size_t clip_rows = (size_t)T * HW;
+  // (plain ints, not L:: constants, inside the scalar-offset arguments of the buffer builtins below: with a template-dependent
+  //  constant expression there the HOST pass of hipcc silently drops the kernel's stub from the object -- no diagnostic)
+  const int rb3 = L::RB3, cb = C * 2, n1b = N1 * 2;
+
+  auto tile_of = [&](int s, int *clip, int *p0) {
+    int tile = bid + s * nwg;
+    if (tile >= ntiles) tile = ntiles - 1;                // (s == my: staged dead, kept in range for the arithmetic)
+    if (p.reverse) tile = ntiles - 1 - tile;
+    *clip = tile / tpc;
+    *p0 = (tile - *clip * tpc) << lpx;
+  };
+  auto issue_w3 = [&](int nc, unsigned dead) {
+#pragma unroll
+    for (int i = 0; i < L::NW3; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW3, (lds_void *)(lds + L::kW3 + (wave * L::NW3 + i) * 1024), 16,
+                                               (int)(w3off[i] | dead), nc * 64 * rb3, 0, 0);
+  };
+  auto issue_w1 = [&](int nc) {
+#pragma unroll
+    for (int i = 0; i < L::NW1; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW1, (lds_void *)(lds + L::kW1 + (wave * L::NW1 + i) * 1024), 16,
+                                               (int)w1off[i], nc * 128, 0, 0);
+  };
+  // pieces i0 .. i0 + n - 1 of the t2 tile (clip, p0) into the staging buffer
+  auto issue_t2 = [&](int clip, int p0, int i0, int n, unsigned dead) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.t2) + (size_t)clip * clip_rows * L::RB3), 0, (int)(clip_rows * L::RB3), 0x00020000);
+    for (int i = i0; i < i0 + n; ++i) {
+      const int row = 32 * wave + i * L::RPP3 + lane / L::LPR3, slot = lane % L::LPR3;
+      const int t = row >> lpx, px = row & (PX - 1);
+      const unsigned off = (unsigned)((t * HW + px) * L::RB3 + ((slot ^ (row & 15)) << 4));
+      const unsigned inv = p0 + px < HW ? 0u : kInvalid;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + L::kT2 + (wave * 8 + i) * 1024), 16, (int)(off | inv | dead),
+                                               p0 * rb3, 0, 0);
+    }
+  };
+  u32x4 rres[4];
+  auto load_res = [&](int q, int clip, int p0, int nc, unsigned dead) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.res) + (size_t)clip * clip_rows * (C * 2)), 0, (int)(clip_rows * (C * 2)), 0x00020000);
+    const unsigned inv = (unsigned)p0 + epx[q] < (unsigned)HW ? 0u : kInvalid;
+    rres[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(evoff[q] | inv | dead), p0 * cb + nc * 128, 0);
+  };
+
+  // ---- prologue: the first tile's t2, the first chunk of W3, the first chunk's residual ----------------------------
+  int clip, p0, nclip, np0;
+  tile_of(0, &clip, &p0);
+  issue_t2(clip, p0, 0, L::NT2, 0u);
+  issue_w3(0, 0u);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) load_res(q, clip, p0, 0, 0u);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  float *Cs = reinterpret_cast<float *>(lds + L::kSlab + wave * 2176);   // this wave's [8][68] fp32 sub-slab
+  for (int s = 0; s < my; ++s) {
+    const unsigned next_dead = s + 1 < my ? 0u : kInvalid;
+    tile_of(s + 1, &nclip, &np0);
+    // GEMM1's A operand: this wave's 32 rows of t2, once per tile, from the staging buffer (every wave's pieces landed
+    // behind counted waits and barriers of the previous tile's second half -- or the prologue's drain)
+    u32x4 afr[L::KT1];
+#pragma unroll
+    for (int g = 0; g < L::KT1; ++g)
+      afr[g] = *reinterpret_cast<const u32x4 *>(lds + t2rd + (((2 * g + half) ^ rflip) << 4));
+    f32x16 acc2[N1 / 32];
+#pragma unroll
+    for (int j = 0; j < N1 / 32; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[j][e] = 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the staging buffer is refilled from chunk 0's epilogue on: behind barrier A)
+    const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(p.y) + (size_t)clip * clip_rows * (C * 2), 0, (int)(clip_rows * (C * 2)), 0x00020000);
+    unsigned einv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) einv[q] = (unsigned)p0 + epx[q] < (unsigned)HW ? 0u : kInvalid;
+
+    for (int nc = 0; nc < L::NC; ++nc) {
+      // vector-memory operations of this wave that are younger than the ones awaited below (see the issue order above)
+      const int pprev = nc > 0 ? c31_pieces(nc - 1) : 0;                   // (chunk NC - 1 of the previous tile issued no t2 piece)
+      const int tail = (nc == 0 && s > 0) ? L::NT1S : 0;                   // the previous tile's t1 stores
+      wait_vmcnt_any(8 + pprev + tail);                                    // W3's chunk nc has landed (this wave's pieces)
+      __builtin_amdgcn_s_barrier();                                        // A: ... everybody's; GEMM2 of chunk nc - 1 is over
+      issue_w1(nc);
+      // ---- GEMM1: y[rows of this wave][64 channels of the chunk] ----
+      f32x16 acc1[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
+#pragma unroll
+      for (int g = 0; g < L::KT1; ++g) {
+        const unsigned sl = ((2 * g + half) ^ rflip) << 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const u32x4 b = *reinterpret_cast<const u32x4 *>(lds + w3rd + j * 32 * L::RB3 + sl);
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[g]), __builtin_bit_cast(bf16x8, b), acc1[j], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                        // B: every wave has read W3's chunk
+      const bool last = nc + 1 == L::NC;
+      issue_w3(last ? 0 : nc + 1, last ? next_dead : 0u);
+      // ---- epilogue of the chunk: + bias3, + residual, ReLU, bf16 -> y (global) and the LDS tile ----
+      const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(bias3_l + nc * 64 + c8 * 8);
+      const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(bias3_l + nc * 64 + c8 * 8 + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cs[(4 * half + r) * 68 + j * 32 + l31] = acc1[j][4 * q + r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (same wave wrote it: no barrier needed)
+        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8);
+        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8 + 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // read before the next sub-slab overwrites it
+        wait_vmcnt_any(6 + pprev + tail + L::NW1 + L::NW3);                // this sub-slab's residual (requested one chunk ago)
+        float v[8] = {c0[0] + bias0[0], c0[1] + bias0[1], c0[2] + bias0[2], c0[3] + bias0[3],
+                      c1[0] + bias1[0], c1[1] + bias1[1], c1[2] + bias1[2], c1[3] + bias1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += split_elem(rres[q], e);
+        u32x4 o;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) o[w2] = pack_bf16(fmaxf(v[2 * w2], 0.f), fmaxf(v[2 * w2 + 1], 0.f));
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(evoff[q] | einv[q]), p0 * cb + nc * 128, 0);
+        *reinterpret_cast<u32x4 *>(lds + yw[q]) = o;
+        if (last) load_res(q, nclip, np0, 0, next_dead);
+        else load_res(q, clip, p0, nc + 1, 0u);
+      }
+      if (c31_pieces(nc) > 0) issue_t2(nclip, np0, 2 * nc, 2, next_dead);
+      wait_vmcnt_any(L::NW3 + 8 + c31_pieces(nc));                         // W1's chunk nc has landed (this wave's pieces)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // ... and this wave's rows of the LDS tile are written
+      __builtin_amdgcn_s_barrier();                                        // C
+      // ---- GEMM2: t1 += shift(y chunk) * W1[:, chunk]^T ----
+      const int c0ch = nc * 64;
+      const int sel = c0ch < p.fold ? 1 : (c0ch < 2 * p.fold ? 2 : 0);     // wave-uniform: frames t + 1 / t - 1 / t
+      const unsigned yb = sel == 1 ? ybase[1] : sel == 2 ? ybase[2] : ybase[0];
+      const unsigned yf = sel == 1 ? yflip[1] : sel == 2 ? yflip[2] : yflip[0];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const u32x4 a = *reinterpret_cast<const u32x4 *>(lds + yb + (((2 * g + half) ^ yf) << 4));
+        const unsigned sl = ((2 * g + half) ^ w1flip) << 4;
+#pragma unroll
+        for (int j = 0; j < N1 / 32; ++j) {
+          const u32x4 b = *reinterpret_cast<const u32x4 *>(lds + w1rd + j * 32 * 128 + sl);
+          acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc2[j], 0, 0, 0);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // ---- t1 of the tile: relu(acc2 + bias1) -> bf16, whole 128-byte row segments ----
+    const __amdgpu_buffer_rsrc_t rsrcT1 = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(p.t1) + (size_t)clip * clip_rows * (N1 * 2), 0, (int)(clip_rows * (N1 * 2)), 0x00020000);
+#pragma unroll
+    for (int jh = 0; jh < N1 / 64; ++jh) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias1_l + jh * 64 + c8 * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias1_l + jh * 64 + c8 * 8 + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cs[(4 * half + r) * 68 + j * 32 + l31] = acc2[2 * jh + j][4 * q + r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8);
+        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8 + 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const float v[8] = {c0[0] + b0[0], c0[1] + b0[1], c0[2] + b0[2], c0[3] + b0[3],
+                            c1[0] + b1[0], c1[1] + b1[1], c1[2] + b1[2], c1[3] + b1[3]};
+        u32x4 o;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) o[w2] = pack_bf16(fmaxf(v[2 * w2], 0.f), fmaxf(v[2 * w2 + 1], 0.f));
+        const unsigned off = ((evoff[q] - (unsigned)(c8 * 16)) >> L::LOG_C_N1) + (unsigned)(c8 * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcT1, (int)(off | einv[q]), p0 * n1b + jh * 128, 0);
+      }
+    }
+    clip = nclip;
+    p0 = np0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the dead tail stages (zeros) land before the workgroup leaves its LDS
+}
+
+bool conv31_valid(const Conv31Params &p) {
+  if (!(p.K3 == 128 && p.C == 512 && p.N1 == 128)) return false;            // instantiated: layer2's non-first blocks
+  if (p.n_clips <= 0 || p.HW <= 0 || p.T <= 0 || 256 % p.T != 0 || 256 / p.T < 8) return false;
+  if (p.fold != 0 && (p.fold % 64 != 0 || 2 * p.fold > p.C)) return false;  // a 64-channel chunk is shifted as a whole
+  return (double)p.T * p.HW * p.C * 2.0 < 2.0e9;                             // 32-bit offsets inside a clip's block
+}
+
+hipError_t launch_conv31_fused(const Conv31Params &p_in, hipStream_t s) {
+  Conv31Params p = p_in;
+  if (!p.t2 || !p.w3 || !p.bias3 || !p.res || !p.y || !p.w1 || !p.bias1 || !p.t1 || !conv31_valid(p)) return hipErrorInvalidValue;
+  const int px = 256 / p.T;
+  p.log_px = 0;
+  while ((1 << p.log_px) < px) ++p.log_px;
+  const DeviceInfo &di = device_info();
+  if (di.status != hipSuccess) return di.status;
+  const long ntiles = (long)p.n_clips * ((p.HW + px - 1) / px);
+  const dim3 grid((unsigned)(ntiles < di.n_cu ? ntiles : di.n_cu)), block(512);
+  constexpr size_t kLdsBytes = C31<128, 512, 128>::kBytes;
+  hipLaunchKernelGGL((conv31_fused_kernel<128, 512, 128>), grid, block, kLdsBytes, s, p);
+  return hipGetLastError();
+}
+
+hipError_t opt_in_conv31() {
+  return lds_opt_in(reinterpret_cast<const void *>(&conv31_fused_kernel<128, 512, 128>), C31<128, 512, 128>::kBytes);
+}
 
 }  // namespace tsm

@@ -119,6 +119,7 @@ struct tsm_engine {
   bool zigzag = true;
   int fuse23 = -1;   // TSM_FUSE_CONV23: 0 never, 1 wherever a block is eligible, unset: the autotuner times both forms
   int fuse_block = -1;   // TSM_FUSE_BLOCK: the same for the whole-Bottleneck kernel (bf16, layer1.1 / layer1.2)
+  int fuse31 = -1;       // TSM_FUSE_C3C1: the same for conv3 of block b + shift + conv1 of block b + 1 as one launch (bf16, layer2)
   int n_cu = 256;
   int timing_left = 0;
   bool timing_only3x3 = false;
@@ -362,7 +363,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   // against THIS layer: anything else falls back to the heuristic shape, so a stale, foreign or hand-edited cache
   // line can only cost speed.
   auto code_ok = [&](const tsm::ConvParams &p, int code) {
-    return code > 0 && (code & ~0xD0F) == 0 && tsm::conv_tile_valid(p, code & 15);   // (0x400 / 0x800: conv2 + conv3 / the whole block run fused, below)
+    return code > 0 && (code & ~0x1D0F) == 0 && tsm::conv_tile_valid(p, code & 15);   // (0x400 / 0x800 / 0x1000: conv2 + conv3 / the whole block / conv3 + the next block's conv1 run fused, below)
   };
   int flip = 0;   // alternates the tile walk direction of consecutive conv launches (ConvParams::reverse)
   auto conv = [&](int idx, tsm::ConvParams p, int ks, bool is3x3) -> int {
@@ -453,11 +454,32 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   for (int li = 0; li < 4; ++li)
     for (int bi = 0; bi < kBlocks[li]; ++bi) block_names.push_back("layer" + std::to_string(li + 1) + "." + std::to_string(bi));
   bool tapped = false;
+  // conv3 of block k and shift + conv1 of block k + 1 as ONE launch (bf16: tsm::launch_conv31_fused): `t1_ready` says that
+  // the previous block's conv3 launch has already left this block's conv1 output in t1; `prev3` keeps the previous block's
+  // conv3 launch for the tuner's A/B at the head of the next block.
+  bool t1_ready = false;
+  struct Prev3 {
+    bool ok = false;
+    tsm::ConvParams p3{};
+    int conv3_idx = -1;
+  } prev3;
+  auto make_p31 = [&](const tsm::ConvParams &p3, const ConvLayer &c1n, float *t1_out, int nn, int hw) {
+    tsm::Conv31Params q{};
+    q.t2 = p3.x; q.w3 = p3.w; q.bias3 = p3.bias; q.res = p3.res; q.y = p3.y;
+    q.w1 = c1n.d_w; q.bias1 = c1n.d_b; q.t1 = t1_out;
+    q.n_clips = nn / T; q.T = T; q.HW = hw; q.K3 = p3.C; q.C = p3.Cout; q.N1 = c1n.cout;
+    q.fold = shiftT > 0 ? c1n.cp / cfg.shift_div : 0;
+    return q;
+  };
   // One Bottleneck on nn frames: x -> y through the branch temporaries t1, t2 (and idb for an un-fused downsample).
   auto run_block = [&](size_t k, int nn, float *x, float *y, int hh, int ww) -> int {
     const Block &blk = e->blocks[k];
     const std::string &name = block_names[k];
     const ConvLayer &c1 = e->convs[blk.conv1], &c2 = e->convs[blk.conv2], &c3 = e->convs[blk.conv3];
+    const bool have_t1 = t1_ready;
+    t1_ready = false;
+    const Prev3 prev = prev3;    // (consumed here whatever path this block takes)
+    prev3.ok = false;
     const int ho = (hh + 2 - 3) / blk.stride + 1, wo = (ww + 2 - 3) / blk.stride + 1;
     const float *identity = x;
     const bool fused = blk.down >= 0 && blk.d_wf != nullptr;
@@ -493,8 +515,43 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       return TSM_OK;
     }
     const int r1 = e->zigzag ? (flip ^ 1) : 0;   // the walk direction conv() is about to give conv1 (kept for the tuner's A/B below)
-    int rc1 = conv(blk.conv1, p1, 1, false);
-    if (rc1) return rc1;
+    if (have_t1) {               // the previous block's conv3 launch computed this conv1 as well: keep the launch slot
+      if (e->cur_timing) {
+        e->cur_timing->push_back(nullptr);
+        e->cur_timing->push_back(nullptr);
+      }
+    } else {
+      int rc1 = conv(blk.conv1, p1, 1, false);
+      if (rc1) return rc1;
+    }
+    if (tuning && prev.ok && e->fuse31 < 0) {
+      // conv3 of the previous block + this conv1 as one launch against the two tuned launches, same protocol as the other
+      // fused forms (both arms rewrite the same bits into the previous block's output and into t1, so re-running is harmless)
+      tsm::Conv31Params q = make_p31(prev.p3, c1, t1, nn, hh * ww);
+      if (tsm::conv31_valid(q)) {
+        const int code3 = (*tiles)[prev.conv3_idx], code1 = (*tiles)[blk.conv1];
+        tsm::ConvParams pa = prev.p3, pc = p1;
+        pc.reverse = e->zigzag ? (pa.reverse ^ 1) : 0;
+        q.reverse = pa.reverse;
+        float pair_ms = 0.f, one_ms = 0.f, ms[4];
+        for (int arm = 0; arm < 2; ++arm) {
+          for (int rep = 0; rep < 4; ++rep) {
+            TSM_HIP(e, hipEventRecord(e->ev0, s));
+            if (arm == 0) {
+              TSM_HIP(e, launch_code(pa, 1, code3));
+              TSM_HIP(e, launch_code(pc, 1, code1));
+            } else {
+              TSM_HIP(e, tsm::launch_conv31_fused(q, s));
+            }
+            TSM_HIP(e, hipEventRecord(e->ev1, s));
+            TSM_HIP(e, hipEventSynchronize(e->ev1));
+            TSM_HIP(e, hipEventElapsedTime(&ms[rep], e->ev0, e->ev1));
+          }
+          (arm == 0 ? pair_ms : one_ms) = std::min(ms[1], std::min(ms[2], ms[3]));
+        }
+        if (one_ms < pair_ms) (*tiles)[prev.conv3_idx] |= 0x1000;
+      }
+    }
     if (want(name + ".conv1")) { tapped = true; return hit(t1, nn, hh, ww, c1.cout); }
     tsm::ConvParams p2 = make_params(c2, t1, nullptr, t2, nn, hh, ww, true, 0, 1, prec);
     // conv2 + conv3 + residual in one kernel where the block is eligible: bit 0x400 of conv2's tile code (set by the
@@ -526,8 +583,35 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       p3.w = blk.d_wf; p3.bias = blk.d_bf; p3.Kp = blk.kpf; p3.K1 = c3.kp; p3.kseg_len = blk.ksegf;
       p3.x2 = x; p3.C2 = cd.cp; p3.Hi2 = hh; p3.Wi2 = ww; p3.stride2 = blk.stride;
     }
-    int rc3 = conv(blk.conv3, p3, 1, false);
-    if (rc3) return rc3;
+    // conv3 + residual of this block and shift + conv1 of the NEXT block as one launch (bf16, no downsample branch on either
+    // side of the boundary geometry-wise: the next block keeps this block's frame size): bit 0x1000 of conv3's tile code
+    // (set by the tuning pass at the head of the next block), or forced / forbidden through TSM_FUSE_C3C1
+    bool did31 = false;
+    if (prec == tsm::kPrecBf16 && !fused && blk.down < 0 && k + 1 < e->blocks.size() && e->fuse31 != 0 &&
+        e->blocks[k + 1].stride == 1 && e->blocks[k + 1].down < 0) {
+      const ConvLayer &c1n = e->convs[e->blocks[k + 1].conv1];
+      tsm::Conv31Params q = make_p31(p3, c1n, t1, nn, ho * wo);
+      if (tsm::conv31_valid(q)) {
+        if (tuning) {
+          prev3.ok = true;
+          prev3.conv3_idx = blk.conv3;
+        } else if (e->fuse31 == 1 || (tiles && ((*tiles)[blk.conv3] & 0x1000))) {
+          q.reverse = e->zigzag ? (flip ^= 1) : 0;
+          TSM_LAUNCH_K(e, s, false, tsm::launch_conv31_fused(q, s));
+          did31 = true;
+          t1_ready = true;
+        }
+      }
+    }
+    if (!did31) {
+      const int r3 = e->zigzag ? (flip ^ 1) : 0;
+      int rc3 = conv(blk.conv3, p3, 1, false);
+      if (rc3) return rc3;
+      if (prev3.ok) {
+        prev3.p3 = p3;
+        prev3.p3.reverse = r3;
+      }
+    }
     if (tuning && ((can_fuse && e->fuse23 < 0) || (can_block && e->fuse_block < 0))) {
       // Fused forms against the tuned separate launches (same bits), under ONE protocol: four repetitions, the first
       // discarded, best of the other three, and a sequence of launches timed back to back inside one event bracket (so
@@ -687,6 +771,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (const char *fc = getenv("TSM_CONV_CODE")) e->force_code = atoi(fc);
   if (const char *f23 = getenv("TSM_FUSE_CONV23")) e->fuse23 = atoi(f23) != 0;
   if (const char *fb = getenv("TSM_FUSE_BLOCK")) e->fuse_block = atoi(fb) != 0;
+  if (const char *f31 = getenv("TSM_FUSE_C3C1")) e->fuse31 = atoi(f31) != 0;
   if (const char *zz = getenv("TSM_ZIGZAG")) e->zigzag = atoi(zz) != 0;
   // TSM_TUNE_CACHE=<file> names the tune cache; unset: a per-user default ($XDG_CACHE_HOME or $HOME/.cache, then
   // tsm_hip/tune_cache.txt), so that the second process on a machine pays no tuning pass; "", "0" or "off" disables it.
@@ -706,7 +791,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
                   (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess ? std::string(prop.gcnArchName) : "?") +
                   " T" + std::to_string(cfg->num_segments) + " " + std::to_string(cfg->height) + "x" +
                   std::to_string(cfg->width) + " dtype" + std::to_string(cfg->dtype) + " shift" +
-                  std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0) + "/" + std::to_string(e->fuse23) + "/" + std::to_string(e->fuse_block);
+                  std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0) + "/" + std::to_string(e->fuse23) + "/" + std::to_string(e->fuse_block) + "/" + std::to_string(e->fuse31);
   }
   build_topology(e);
   st = hipSetDevice(cfg->device_id);

@@ -109,6 +109,28 @@ struct BneckParams {
 bool bneck_ws_valid(int cin, int n, int h, int w, int T, int fold);
 hipError_t launch_bneck_ws(const BneckParams &p, hipStream_t s);
 
+// conv3 + bn3 + residual + ReLU of Bottleneck b AND temporal shift + conv1 + bn1 + ReLU of Bottleneck b + 1 as ONE launch
+// (bf16, conv31_fused_kernel, tsm_conv31.hip): the block output y is written once (block b + 1's identity) and never read
+// back for conv1 -- a tile is all T frames of a clip x 256 / T pixels, so the frames t +- 1 the shifted channels come from
+// are rows of the same tile.  Bit-identical to launch_conv(conv3 with residual) followed by launch_conv(conv1 with shift).
+struct Conv31Params {
+  const void *t2;      // [F * HW, K3] bf16: conv3's input (conv2's output of block b)
+  const void *w3;      // [C][K3] bf16, bn3 scale folded in
+  const float *bias3;  // [C]
+  const void *res;     // [F * HW, C] bf16: block b's input (the identity branch)
+  void *y;             // [F * HW, C] bf16: block b's output
+  const void *w1;      // [N1][C] bf16: conv1 of block b + 1, bn1 scale folded in
+  const float *bias1;  // [N1]
+  void *t1;            // [F * HW, N1] bf16: conv1's output of block b + 1
+  int n_clips, T, HW;  // F = n_clips * T frames of HW pixels
+  int K3, C, N1;
+  int fold;            // channels [0, fold) of conv1's input come from frame t + 1, [fold, 2 fold) from t - 1 (0: no shift)
+  int reverse;         // walk the tiles from the last one to the first
+  int log_px;          // (set by the launcher: log2(256 / T))
+};
+bool conv31_valid(const Conv31Params &p);
+hipError_t launch_conv31_fused(const Conv31Params &p, hipStream_t s);
+
 // Stem (7x7 s2 p3, 3 -> 64) of the bf16 formats as a direct convolution from an LDS-resident pixel-pair patch; x is the
 // packed-pair input [n][hi][ceil(wi/2)][8], w the engine's packed stem weights [64][kp], y NHWC, all in `prec`'s format
 // (kPrecBf16 or kPrecBf16x3).  Bit-identical to launch_conv(ks = 7) on the same operands.

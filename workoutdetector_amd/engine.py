@@ -233,9 +233,11 @@ class TsmEngine:
         """``tile + 256 * split``: '64x64/splitK' = one workgroup per (tile, K segment), combined in segment order
         (segmented fp32 layers at small batch); '+conv3' on a block's conv2 = conv2 + conv3 + residual run as one fused
         kernel (the conv3 entry of that block is then unused); '+block' on a block's conv1 = the whole Bottleneck runs as one
-        launch (bf16 layer1.1 / layer1.2; the conv2 / conv3 entries are then unused)."""
+        launch (bf16 layer1.1 / layer1.2; the conv2 / conv3 entries are then unused); '+conv1' on a block's conv3 = that
+        launch also runs the NEXT block's shift + conv1 (bf16 layer2: conv31_fused_kernel; the next block's conv1 entry is then
+        unused)."""
         return (cls.TILE_NAMES[code & 15] + ('/splitK' if code & 0x100 else '') + ('+conv3' if code & 0x400 else '') +
-                ('+block' if code & 0x800 else ''))
+                ('+block' if code & 0x800 else '') + ('+conv1' if code & 0x1000 else ''))
 
     def conv_tiles(self, n_clips: int) -> Dict[str, str]:
         """Tile shape the autotuner chose per conv launch for an ``n_clips`` forward."""

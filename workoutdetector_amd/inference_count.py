@@ -669,6 +669,14 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
     # (the stager's worker starts on the first video here, before the host-side setup below)
     pieces = prefetch_pieces(model, ((v, (lambda p=items[v].video_path: reader(p))) for v in mine))
     try:
+        if dev is not None and hasattr(model, 'warmup') and mine:
+            # Cold-job costs out of the loop: the kernels of the two batch sizes this rank will run -- full
+            # batches and the ragged last one -- are tuned (tsm_tune: the engine's own zeroed buffer, no torch kernel) or
+            # read from the tune cache NOW, while the stager's worker reads, pins and uploads the first pieces; without
+            # this the first batch and the last batch of every cold job each stopped for a tuning pass mid-loop.
+            my_clips = sum(counts[v] for v in mine)
+            tail = my_clips % batch_clips
+            model.warmup(sorted({b for b in (min(batch_clips, my_clips), tail) if b > 0}))
         return _run_global(model, items, mine, counts, pieces, out_dir, checkpoint, transform, batch_clips, dev, rank, world)
     finally:
         pieces.close()       # (a failure anywhere below must not leave the stager blocked on its full queue)
