@@ -408,7 +408,9 @@ def test_conv3_conv1_cross_block_kernel_equals_the_separate_launches_bitwise(hip
     from workoutdetector_amd.weights import make_state_dict
     sd = make_state_dict(13, 12)
     x = make_input(700 + h + t, b, t, h, w)
-    stages = ('layer2.0', 'layer2.1', 'layer2.2.conv1', 'layer2.2', 'layer2.3.conv1', 'layer2.3', 'layer3.0')
+    # (layer2.k -> k+1 on the 8-wave form; layer2.3 -> layer3.0.conv1 and layer3.k -> k+1 on the 4-wave forms, 128-row tiles)
+    stages = ('layer2.0', 'layer2.1', 'layer2.2.conv1', 'layer2.2', 'layer2.3.conv1', 'layer2.3', 'layer3.0.conv1', 'layer3.0',
+              'layer3.1', 'layer3.2.conv1', 'layer3.2', 'layer3.4', 'layer3.5.conv1', 'layer3.5', 'layer4.0')
     got = {}
     for flag in ('1', '0'):
         monkeypatch.setenv('TSM_FUSE_C3C1', flag)
@@ -431,7 +433,8 @@ def test_tuner_may_choose_the_cross_block_kernel_and_reports_it(hip_lib, sd0):
     tiles = eng.conv_tiles(4)
     eng.close()
     fused = [k for k, v in tiles.items() if v.endswith('+conv1')]
-    assert all(k in ('layer2.1.conv3', 'layer2.2.conv3') for k in fused), fused
+    assert all(k in ('layer2.1.conv3', 'layer2.2.conv3', 'layer2.3.conv3', 'layer3.1.conv3', 'layer3.2.conv3', 'layer3.3.conv3',
+                     'layer3.4.conv3') for k in fused), fused
     os.environ['TSM_FUSE_C3C1'] = '0'
     try:
         ref = TsmEngine(num_segments=16, height=256, width=256, max_clips=4, state_dict=sd0, dtype='bf16')

@@ -28,10 +28,10 @@ for flag in ('0', '1', '0', '1'):
         eng.forward_device(x, out=out)
         ms.append(eng.last_forward_ms)
     per = [eng.layer_times_ms(i) for i in range(8)]
-    names = [k for k in per[0] if k.startswith('layer2.')]
+    names = [k for k in per[0] if k.startswith(('layer2.', 'layer3.'))]
     med = {k: sorted(p[k] for p in per)[4] for k in names}
     print(f'TSM_FUSE_C3C1={flag}: forward {sorted(ms)[4]:.3f} ms; ' +
-          ' '.join(f'{k[7:]}={v * 1e3:.0f}' for k, v in med.items() if v > 0), flush=True)
+          ' '.join(f'{k[5:]}={v * 1e3:.0f}' for k, v in med.items() if v > 0), flush=True)
     res.setdefault(flag, []).append((sorted(ms)[4], out.clone()))
     eng.close()
 assert torch.equal(res['0'][0][1], res['1'][0][1]), 'fused != separate'

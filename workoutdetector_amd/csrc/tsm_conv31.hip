@@ -1,5 +1,5 @@
 // conv31_fused_kernel: Bottleneck.conv3 + bn3 + residual + ReLU of block b  AND  temporal shift + conv1 + bn1 + ReLU of
-// block b + 1 in ONE launch (bf16; layer2's non-first blocks).
+// block b + 1 in ONE launch (bf16; layer2 / layer3 blocks without a downsample branch).
 #include "tsm_device.h"
 
 namespace tsm {
@@ -10,15 +10,20 @@ namespace tsm {
 // back one launch later (1.07 GB per block at the config-5 size).  Fusing the two across the block boundary looked
 // forbidden -- conv1 reads its first C/8 channels from frame t + 1 and the next C/8 from frame t - 1 (models/tsm.py:35-50),
 // so a SPATIAL tile of y does not hold conv1's input.  A CLIP-MAJOR tile does: a tile here is ALL T frames of one clip x
-// PX consecutive pixels (T * PX = 256 rows, row = t * PX + px), and the shifted channels of row (t, px) are the same
+// PX consecutive pixels (T * PX = 256 or 128 rows, row = t * PX + px), and the shifted channels of row (t, px) are the same
 // channels of rows (t +- 1, px) of the SAME tile -- a row offset of +- PX inside the tile, zeros where t +- 1 leaves the clip.
 //
-// One persistent 8-wave workgroup per CU; wave w owns tile rows 32 w .. 32 w + 31 in both GEMMs.  Per tile:
-//   * t2 (conv3's input, [256][K3] bf16) arrives by LDS-DMA in a staging buffer a whole tile ahead and is read ONCE into
-//     registers as the A fragments of GEMM1 (K3 / 16 fragments per lane);
+// One persistent 8-wave workgroup per CU (two waves per SIMD, <= 256 registers each).  CH = 1 (N1 = 128): tiles of 256
+// rows, wave w owns rows 32 w .. 32 w + 31 in both GEMMs.  CH = 2 (N1 = 256: GEMM2's 32 x 256 accumulator does not fit one
+// wave): tiles of 128 rows, the two waves of a PAIR share 32 rows and split the columns of both GEMMs (GEMM1: 32 of the
+// chunk's 64 channels each, GEMM2: 128 of the 256 output channels each); the chunk's epilogue is split by rows, 16 each.
+// Per tile:
+//   * t2 (conv3's input, [rows][K3] bf16) is read ONCE into registers as the A fragments of GEMM1 (K3 / 16 fragments per
+//     lane): CH = 1 through an LDS staging buffer filled by LDS-DMA a whole tile ahead; CH = 2 (no LDS left for that) by
+//     16-byte loads issued right after the last GEMM1 of the previous tile, under that chunk's epilogue and GEMM2;
 //   * the block channels are walked in chunks of 64:  GEMM1  y[:, chunk] = t2 * W3[chunk, :]^T  (16 MFMAs per wave, B
-//     fragments from the chunk of W3 that LDS-DMA brought in during the previous chunk);  epilogue through a wave-private
-//     [8][68] fp32 sub-slab: + bias3, + residual (16 bytes per lane = whole 128-byte row segments per 8 lanes, loaded into
+//     fragments from the chunk of W3 that LDS-DMA brought in during the previous chunk);  epilogue through an fp32 LDS slab
+//     (CH = 1: wave-private [8][68] sub-slabs; CH = 2: the pair's [32][68]): + bias3, + residual (16 bytes per lane = whole 128-byte row segments per 8 lanes, loaded into
 //     registers one chunk ahead), ReLU, bf16 -> (a) stored to y (the next block's identity needs it: written once, never
 //     re-read by this kernel), (b) written to a [256][64] bf16 LDS tile;  GEMM2  t1 += shift(y[:, chunk]) * W1[:, chunk]^T
 //     (16 MFMAs per wave; the A fragments are rows r, r + PX or r - PX of the LDS tile according to the chunk's place in
@@ -27,42 +32,49 @@ namespace tsm {
 // HBM bytes per tile row: K3*2 (t2) + C*2 (residual) + C*2 (y) + N1*2 (t1) against + C*2 more for the two launches it
 // replaces; the weights (C*K3 + N1*C elements per tile) stream from L2.  Three barriers per chunk; every vector-memory
 // wait is a counted vmcnt over the fixed issue order of a chunk
-//     [W1 chunk: NW1 DMA | W3 next chunk: NW3 DMA | (store y, load next residual) x 4 | t2 of the next tile: P DMA],
+//     [W1 chunk: NW1 DMA | W3 next chunk: NW3 DMA | CH = 2, last chunk: the next tile's A fragments |
+//      (store y, load next residual) x 4 / CH | CH = 1: t2 of the next tile, P DMA],
 // never vmcnt(0) inside the loop: the residual stream, the weight stream and the next tile's t2 stay in flight under
 // both GEMMs and the epilogue.
 // Products enter every accumulator in the separate kernels' order (k16 groups ascending from a zero accumulator) and the
 // two epilogues are theirs (conv_bf16_256p's residual arm; its shifted-conv1 arm): bit-identical to the two launches.
-// Needs T | 256 with 8 <= 256 / T (all frames of a clip in one tile), fold % 64 == 0 (a chunk is shifted as a whole).
+// Needs T | rows with 8 <= rows / T (all frames of a clip in one tile), fold % 64 == 0 (a chunk is shifted as a whole).
 // ---------------------------------------------------------------------------------------------
-template <int K3, int C, int N1> struct C31 {
-  static constexpr int M = 256;                    // tile rows = T frames x PX pixels
+template <int K3, int C, int N1, int CH> struct C31 {
+  static constexpr int NW = 8;                     // waves
+  static constexpr int M = 32 * NW / CH;           // tile rows = T frames x PX pixels
+  static constexpr int NT = 64 * NW;               // threads
+  static constexpr bool STAGE = CH == 1;           // t2 through an LDS staging buffer (else straight into registers)
   static constexpr int KT1 = K3 / 16;              // k16 steps of GEMM1
   static constexpr int NC = C / 64;                // chunks of the block's channels
+  static constexpr int NTL1 = 2 / CH;              // GEMM1 N-tiles per wave (of the chunk's two)
+  static constexpr int NTL2 = N1 / 32 / CH;        // GEMM2 N-tiles per wave
+  static constexpr int NQ = 4 / CH;                // 8-row epilogue steps per wave and chunk
   static constexpr int RB3 = K3 * 2;               // bytes per row of t2 / of W3
   static constexpr int LPR3 = RB3 / 16;            // lanes (16-byte slots) per such row
   static constexpr int RPP3 = 1024 / RB3;          // rows per 1-KiB DMA piece
-  static constexpr int NW3 = 64 * RB3 / 1024 / 8;  // DMA pieces per wave: a chunk of W3 (64 rows)
-  static constexpr int NW1 = N1 * 128 / 1024 / 8;  // ... a chunk of W1 (N1 rows x 64 channels)
-  static constexpr int NT2 = M * RB3 / 1024 / 8;   // ... the t2 tile
-  static constexpr int NT1S = 4 * (N1 / 64);       // t1 stores per wave and tile
+  static constexpr int NW3 = 64 * RB3 / 1024 / NW; // DMA pieces per wave: a chunk of W3 (64 rows)
+  static constexpr int NW1 = N1 * 128 / 1024 / NW; // ... a chunk of W1 (N1 rows x 64 channels)
+  static constexpr int NT2 = STAGE ? M * RB3 / 1024 / NW : 0;   // ... the staged t2 tile (the wave's own 32 rows)
+  static constexpr int PT2 = STAGE ? 2 * NT2 / NC : 0;          // t2 pieces of the NEXT tile issued per chunk, in the first NC / 2 chunks
+  static constexpr int AF = STAGE ? 0 : KT1;       // register loads of the next tile's A fragments, in a tile's last chunk
+  static constexpr int NT1S = 4 * (N1 / 64) / CH;  // t1 stores per wave and tile
   static constexpr int LOG_C_N1 = C / N1 == 4 ? 2 : C / N1 == 2 ? 1 : 0;
+  static constexpr int kSlabBytes = STAGE ? NW * 2176 : (NW / CH) * 8704;   // [8][68] per wave / [32][68] per pair, fp32
   static constexpr int kW3 = 0;
   static constexpr int kW1 = kW3 + 64 * RB3;
   static constexpr int kY = kW1 + N1 * 128;
   static constexpr int kT2 = kY + M * 128;
-  static constexpr int kSlab = kT2 + M * RB3;
-  static constexpr int kBias3 = kSlab + 8 * 2176;
+  static constexpr int kSlab = kT2 + (STAGE ? M * RB3 : 0);
+  static constexpr int kBias3 = kSlab + kSlabBytes;
   static constexpr int kBias1 = kBias3 + C * 4;
   static constexpr int kZero = kBias1 + N1 * 4;
   static constexpr int kBytes = kZero + 128;
+  static_assert(CH == 1 || CH == 2, "a wave, or a pair of waves, per 32 tile rows");
   static_assert(C / N1 == 4 || C / N1 == 2, "t1's row offsets are derived from y's by a shift");
-  static_assert(NT2 == 8 && NC >= 5, "the t2 pieces of the next tile ride on chunks 0-3, two per chunk");
+  static_assert(!STAGE || (PT2 * NC == 2 * NT2 && PT2 >= 1 && NC >= 4), "the t2 pieces of the next tile ride on the first half of the chunks");
   static_assert(kBytes <= 160 * 1024, "LDS budget");
 };
-
-// t2 pieces of the NEXT tile issued in chunk nc (all in the first half of the tile, so that they have landed -- behind
-// waits this wave passes anyway -- long before the next tile's first GEMM needs them)
-__device__ __forceinline__ constexpr int c31_pieces(int nc) { return nc < 4 ? 2 : 0; }
 
 __device__ __forceinline__ void wait_vmcnt_any(int n) {
 #define TSM_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
@@ -72,54 +84,61 @@ __device__ __forceinline__ void wait_vmcnt_any(int n) {
     TSM_VMCNT_CASE(12) TSM_VMCNT_CASE(13) TSM_VMCNT_CASE(14) TSM_VMCNT_CASE(15) TSM_VMCNT_CASE(16) TSM_VMCNT_CASE(17)
     TSM_VMCNT_CASE(18) TSM_VMCNT_CASE(19) TSM_VMCNT_CASE(20) TSM_VMCNT_CASE(21) TSM_VMCNT_CASE(22) TSM_VMCNT_CASE(23)
     TSM_VMCNT_CASE(24) TSM_VMCNT_CASE(25) TSM_VMCNT_CASE(26) TSM_VMCNT_CASE(27) TSM_VMCNT_CASE(28) TSM_VMCNT_CASE(29)
-    TSM_VMCNT_CASE(30) TSM_VMCNT_CASE(31) TSM_VMCNT_CASE(32)
+    TSM_VMCNT_CASE(30) TSM_VMCNT_CASE(31) TSM_VMCNT_CASE(32) TSM_VMCNT_CASE(33) TSM_VMCNT_CASE(34) TSM_VMCNT_CASE(35)
+    TSM_VMCNT_CASE(36) TSM_VMCNT_CASE(37) TSM_VMCNT_CASE(38) TSM_VMCNT_CASE(39) TSM_VMCNT_CASE(40) TSM_VMCNT_CASE(41)
+    TSM_VMCNT_CASE(42) TSM_VMCNT_CASE(43) TSM_VMCNT_CASE(44) TSM_VMCNT_CASE(45) TSM_VMCNT_CASE(46) TSM_VMCNT_CASE(47)
+    TSM_VMCNT_CASE(48)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 #undef TSM_VMCNT_CASE
 }
 
-template <int K3, int C, int N1>
+template <int K3, int C, int N1, int CH>
 __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params p) {
-  typedef C31<K3, C, N1> L;
+  typedef C31<K3, C, N1, CH> L;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   typedef __attribute__((address_space(3))) void lds_void;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave / CH, wh = wave % CH;               // row group (32 tile rows) and this wave's share of its columns
   const int half = lane >> 5, l31 = lane & 31, c8 = lane & 7, r8l = lane >> 3;
   const int T = p.T, HW = p.HW;
-  const int lpx = p.log_px, PX = 1 << lpx;               // pixels of a tile: 256 / T
+  const int lpx = p.log_px, PX = 1 << lpx;               // pixels of a tile: rows / T
   const int tpc = (HW + PX - 1) >> lpx;                   // tiles per clip
   const int ntiles = p.n_clips * tpc, nwg = (int)gridDim.x, bid = (int)blockIdx.x;
   const int my = (ntiles - bid + nwg - 1) / nwg;          // tiles of this workgroup (>= 1: the grid never exceeds the tiles)
 
   float *bias3_l = reinterpret_cast<float *>(lds + L::kBias3), *bias1_l = reinterpret_cast<float *>(lds + L::kBias1);
-  for (int i = tid; i < C; i += 512) bias3_l[i] = p.bias3[i];
-  for (int i = tid; i < N1; i += 512) bias1_l[i] = p.bias1[i];
+  for (int i = tid; i < C; i += L::NT) bias3_l[i] = p.bias3[i];
+  for (int i = tid; i < N1; i += L::NT) bias1_l[i] = p.bias1[i];
   if (tid < 32) reinterpret_cast<unsigned *>(lds + L::kZero)[tid] = 0u;
 
   // ---- per-lane constants -------------------------------------------------------------------------------------
-  // epilogue: this lane's row of sub-slab q is tile row 32 wave + 8 q + r8l; it handles channels 8 c8 .. 8 c8 + 7 of a chunk
-  unsigned evoff[4], epx[4], yw[4];
+  // epilogue step q of this wave: row 8 q + r8l of its share of the row group (CH = 1: all 32 rows, CH = 2: 16), channels
+  // 8 c8 .. 8 c8 + 7 of the chunk
+  unsigned evoff[L::NQ], epx[L::NQ], yw[L::NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = 32 * wave + 8 * q + r8l;
+  for (int q = 0; q < L::NQ; ++q) {
+    const int row = 32 * rg + 8 * L::NQ * wh + 8 * q + r8l;
     const int t = row >> lpx, px = row & (PX - 1);
     evoff[q] = (unsigned)((t * HW + px) * (C * 2) + c8 * 16);          // byte offset in the clip's [T*HW][C] block (+ p0 * C * 2)
     epx[q] = (unsigned)px;
     yw[q] = (unsigned)(L::kY + row * 128 + ((c8 ^ ((row >> 1) & 7)) << 4));
   }
-  // GEMM2's A fragments: tile row r = 32 wave + l31 as it stands, or rows r + PX / r - PX (frames t + 1 / t - 1), or zeros
+  // GEMM2's A fragments: tile row r = 32 rg + l31 as it stands, or rows r + PX / r - PX (frames t + 1 / t - 1), or zeros
   unsigned ybase[3], yflip[3];
+  const int arow = 32 * rg + l31;
   {
-    const int r = 32 * wave + l31, t = r >> lpx;
-    const int rp = r + PX, rm = r - PX;
-    ybase[0] = (unsigned)(L::kY + r * 128);   yflip[0] = (unsigned)((r >> 1) & 7);
+    const int t = arow >> lpx, rp = arow + PX, rm = arow - PX;
+    ybase[0] = (unsigned)(L::kY + arow * 128);   yflip[0] = (unsigned)((arow >> 1) & 7);
     ybase[1] = t + 1 < T ? (unsigned)(L::kY + rp * 128) : (unsigned)L::kZero;   yflip[1] = t + 1 < T ? (unsigned)((rp >> 1) & 7) : 0u;
     ybase[2] = t > 0 ? (unsigned)(L::kY + rm * 128) : (unsigned)L::kZero;       yflip[2] = t > 0 ? (unsigned)((rm >> 1) & 7) : 0u;
   }
-  const unsigned w1rd = (unsigned)(L::kW1 + l31 * 128), w1flip = (unsigned)((l31 >> 1) & 7);
-  const unsigned w3rd = (unsigned)(L::kW3 + l31 * L::RB3), rflip = (unsigned)(l31 & 15);
-  const unsigned t2rd = (unsigned)(L::kT2 + (32 * wave + l31) * L::RB3);
+  const unsigned w1rd = (unsigned)(L::kW1 + (wh * (N1 / CH) + l31) * 128), w1flip = (unsigned)((l31 >> 1) & 7);
+  const unsigned w3rd = (unsigned)(L::kW3 + (wh * (64 / CH) + l31) * L::RB3), rflip = (unsigned)(l31 & 15);
+  const unsigned t2rd = (unsigned)(L::kT2 + arow * L::RB3);
+  // direct A-fragment loads (CH = 2): 16 bytes of row `arow`, k16 group g at + 32 g
+  const unsigned afoff = (unsigned)(((arow >> lpx) * HW + (arow & (PX - 1))) * L::RB3 + half * 16), afpx = (unsigned)(arow & (PX - 1));
   // DMA sources (the 16-byte chunk a lane fetches is swizzled on the SOURCE side; the LDS side is linear per piece)
   unsigned w3off[L::NW3], w1off[L::NW1];
 #pragma unroll
@@ -158,7 +177,7 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW1, (lds_void *)(lds + L::kW1 + (wave * L::NW1 + i) * 1024), 16,
                                                (int)w1off[i], nc * 128, 0, 0);
   };
-  // pieces i0 .. i0 + n - 1 of the t2 tile (clip, p0) into the staging buffer
+  // STAGE: pieces i0 .. i0 + n - 1 of the t2 tile (clip, p0) into the staging buffer
   auto issue_t2 = [&](int clip, int p0, int i0, int n, unsigned dead) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.t2) + (size_t)clip * clip_rows * L::RB3), 0, (int)(clip_rows * L::RB3), 0x00020000);
@@ -167,11 +186,20 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
       const int t = row >> lpx, px = row & (PX - 1);
       const unsigned off = (unsigned)((t * HW + px) * L::RB3 + ((slot ^ (row & 15)) << 4));
       const unsigned inv = p0 + px < HW ? 0u : kInvalid;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + L::kT2 + (wave * 8 + i) * 1024), 16, (int)(off | inv | dead),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(lds + L::kT2 + (wave * L::NT2 + i) * 1024), 16, (int)(off | inv | dead),
                                                p0 * rb3, 0, 0);
     }
   };
-  u32x4 rres[4];
+  u32x4 afr[L::KT1];                                      // GEMM1's A operand: this wave's 32 rows of t2, held for a whole tile
+  auto load_afr = [&](int clip, int p0, unsigned dead) {  // !STAGE: straight from global memory
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.t2) + (size_t)clip * clip_rows * L::RB3), 0, (int)(clip_rows * L::RB3), 0x00020000);
+    const unsigned inv = (unsigned)p0 + afpx < (unsigned)HW ? 0u : kInvalid;
+#pragma unroll
+    for (int g = 0; g < L::KT1; ++g)
+      afr[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(afoff | inv | dead), p0 * rb3 + g * 32, 0);
+  };
+  u32x4 rres[L::NQ];
   auto load_res = [&](int q, int clip, int p0, int nc, unsigned dead) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.res) + (size_t)clip * clip_rows * (C * 2)), 0, (int)(clip_rows * (C * 2)), 0x00020000);
@@ -182,75 +210,106 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
   // ---- prologue: the first tile's t2, the first chunk of W3, the first chunk's residual ----------------------------
   int clip, p0, nclip, np0;
   tile_of(0, &clip, &p0);
-  issue_t2(clip, p0, 0, L::NT2, 0u);
+  if constexpr (L::STAGE) issue_t2(clip, p0, 0, L::NT2, 0u);
+  else load_afr(clip, p0, 0u);
   issue_w3(0, 0u);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) load_res(q, clip, p0, 0, 0u);
+  for (int q = 0; q < L::NQ; ++q) load_res(q, clip, p0, 0, 0u);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  float *Cs = reinterpret_cast<float *>(lds + L::kSlab + wave * 2176);   // this wave's [8][68] fp32 sub-slab
+  // fp32 slab of the chunk epilogue: STAGE this wave's own [8][68]; else the pair's [32][68] (its first 2176 bytes per wave
+  // double as the wave's private sub-slab in the t1 epilogue)
+  float *Cs = reinterpret_cast<float *>(lds + L::kSlab + (L::STAGE ? wave * 2176 : rg * 8704));
+  float *Cw = L::STAGE ? Cs : Cs + wh * 544;
   for (int s = 0; s < my; ++s) {
     const unsigned next_dead = s + 1 < my ? 0u : kInvalid;
     tile_of(s + 1, &nclip, &np0);
-    // GEMM1's A operand: this wave's 32 rows of t2, once per tile, from the staging buffer (every wave's pieces landed
-    // behind counted waits and barriers of the previous tile's second half -- or the prologue's drain)
-    u32x4 afr[L::KT1];
+    if constexpr (L::STAGE) {
+      // (every wave's pieces landed behind counted waits and barriers of the previous tile's second half -- or the prologue)
 #pragma unroll
-    for (int g = 0; g < L::KT1; ++g)
-      afr[g] = *reinterpret_cast<const u32x4 *>(lds + t2rd + (((2 * g + half) ^ rflip) << 4));
-    f32x16 acc2[N1 / 32];
+      for (int g = 0; g < L::KT1; ++g)
+        afr[g] = *reinterpret_cast<const u32x4 *>(lds + t2rd + (((2 * g + half) ^ rflip) << 4));
+    }
+    if constexpr (!L::STAGE) {
+      // The A fragments were requested in the previous tile's last chunk.  Consuming them HERE, once per tile, makes the
+      // compiler place its wait for these register loads here too: left to the first MFMA inside the chunk loop, its
+      // loop-carried analysis put a conservative vmcnt(3) in front of EVERY chunk's GEMM1, which also waited for the
+      // residual loads of the chunk -- the stream this kernel lives on.
 #pragma unroll
-    for (int j = 0; j < N1 / 32; ++j)
+      for (int g = 0; g < L::KT1; ++g) asm volatile("" ::"v"(afr[g]));
+    }
+    f32x16 acc2[L::NTL2];
+#pragma unroll
+    for (int j = 0; j < L::NTL2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc2[j][e] = 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the staging buffer is refilled from chunk 0's epilogue on: behind barrier A)
     const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char *>(p.y) + (size_t)clip * clip_rows * (C * 2), 0, (int)(clip_rows * (C * 2)), 0x00020000);
-    unsigned einv[4];
+    unsigned einv[L::NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) einv[q] = (unsigned)p0 + epx[q] < (unsigned)HW ? 0u : kInvalid;
+    for (int q = 0; q < L::NQ; ++q) einv[q] = (unsigned)p0 + epx[q] < (unsigned)HW ? 0u : kInvalid;
 
     for (int nc = 0; nc < L::NC; ++nc) {
       // vector-memory operations of this wave that are younger than the ones awaited below (see the issue order above)
-      const int pprev = nc > 0 ? c31_pieces(nc - 1) : 0;                   // (chunk NC - 1 of the previous tile issued no t2 piece)
+      const bool last = nc + 1 == L::NC;
+      const int pnow = nc < L::NC / 2 ? L::PT2 : 0;                        // t2 pieces of the next tile issued in this chunk
+      const int pprev = (nc > 0 && nc - 1 < L::NC / 2) ? L::PT2 : 0;       // ... in the previous one (chunk NC - 1 of the previous tile: none)
       const int tail = (nc == 0 && s > 0) ? L::NT1S : 0;                   // the previous tile's t1 stores
-      wait_vmcnt_any(8 + pprev + tail);                                    // W3's chunk nc has landed (this wave's pieces)
+      const int afprev = (nc == 0 && s > 0) ? L::AF : 0;                   // ... and this tile's A-fragment loads, issued in its last chunk
+      wait_vmcnt_any(2 * L::NQ + pprev + tail + afprev);                   // W3's chunk nc has landed (this wave's pieces)
       __builtin_amdgcn_s_barrier();                                        // A: ... everybody's; GEMM2 of chunk nc - 1 is over
       issue_w1(nc);
-      // ---- GEMM1: y[rows of this wave][64 channels of the chunk] ----
-      f32x16 acc1[2];
+      // ---- GEMM1: y[rows of this row group][this wave's channels of the chunk] ----
+      f32x16 acc1[L::NTL1];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < L::NTL1; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
 #pragma unroll
       for (int g = 0; g < L::KT1; ++g) {
         const unsigned sl = ((2 * g + half) ^ rflip) << 4;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < L::NTL1; ++j) {
           const u32x4 b = *reinterpret_cast<const u32x4 *>(lds + w3rd + j * 32 * L::RB3 + sl);
           acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[g]), __builtin_bit_cast(bf16x8, b), acc1[j], 0, 0, 0);
         }
       }
+      if constexpr (!L::STAGE) {    // the pair's slab: this wave's 32 columns of all 32 rows, complete behind barrier B
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Cs[((e & 3) + 8 * (e >> 2) + 4 * half) * 68 + wh * 32 + l31] = acc1[0][e];
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                                        // B: every wave has read W3's chunk
-      const bool last = nc + 1 == L::NC;
       issue_w3(last ? 0 : nc + 1, last ? next_dead : 0u);
+      if constexpr (!L::STAGE) {
+        if (last) load_afr(nclip, np0, next_dead);                         // GEMM1 of this tile is over: the next tile's A fragments
+      }
       // ---- epilogue of the chunk: + bias3, + residual, ReLU, bf16 -> y (global) and the LDS tile ----
       const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(bias3_l + nc * 64 + c8 * 8);
       const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(bias3_l + nc * 64 + c8 * 8 + 4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < L::NQ; ++q) {
+        f32x4 c0, c1;
+        if constexpr (L::STAGE) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Cs[(4 * half + r) * 68 + j * 32 + l31] = acc1[j][4 * q + r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (same wave wrote it: no barrier needed)
-        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8);
-        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8 + 4);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // read before the next sub-slab overwrites it
-        wait_vmcnt_any(6 + pprev + tail + L::NW1 + L::NW3);                // this sub-slab's residual (requested one chunk ago)
+            for (int r = 0; r < 4; ++r) Cs[(4 * half + r) * 68 + j * 32 + l31] = acc1[j][4 * q + r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (same wave wrote it: no barrier needed)
+          c0 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8);
+          c1 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8 + 4);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // read before the next sub-slab overwrites it
+        } else {
+          c0 = *reinterpret_cast<const f32x4 *>(Cs + (16 * wh + 8 * q + r8l) * 68 + c8 * 8);
+          c1 = *reinterpret_cast<const f32x4 *>(Cs + (16 * wh + 8 * q + r8l) * 68 + c8 * 8 + 4);
+        }
+        // this step's residual (requested one chunk ago)
+        wait_vmcnt_any(2 * (L::NQ - 1) + pprev + tail + L::NW1 + L::NW3 + (last ? L::AF : 0));
+        // (pins the residual's first use behind the counted wait: the scheduler otherwise hoists its bf16 -> fp32 unpacking into
+        //  GEMM1's MFMA shadow, and the compiler's own wait for these registers then sits in front of GEMM1)
+        asm volatile("" : "+v"(rres[q]));
         float v[8] = {c0[0] + bias0[0], c0[1] + bias0[1], c0[2] + bias0[2], c0[3] + bias0[3],
                       c1[0] + bias1[0], c1[1] + bias1[1], c1[2] + bias1[2], c1[3] + bias1[3]};
 #pragma unroll
@@ -263,8 +322,10 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
         if (last) load_res(q, nclip, np0, 0, next_dead);
         else load_res(q, clip, p0, nc + 1, 0u);
       }
-      if (c31_pieces(nc) > 0) issue_t2(nclip, np0, 2 * nc, 2, next_dead);
-      wait_vmcnt_any(L::NW3 + 8 + c31_pieces(nc));                         // W1's chunk nc has landed (this wave's pieces)
+      if constexpr (L::STAGE) {
+        if (pnow > 0) issue_t2(nclip, np0, L::PT2 * nc, L::PT2, next_dead);
+      }
+      wait_vmcnt_any(L::NW3 + (last ? L::AF : 0) + 2 * L::NQ + pnow);      // W1's chunk nc has landed (this wave's pieces)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // ... and this wave's rows of the LDS tile are written
       __builtin_amdgcn_s_barrier();                                        // C
       // ---- GEMM2: t1 += shift(y chunk) * W1[:, chunk]^T ----
@@ -277,37 +338,40 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
         const u32x4 a = *reinterpret_cast<const u32x4 *>(lds + yb + (((2 * g + half) ^ yf) << 4));
         const unsigned sl = ((2 * g + half) ^ w1flip) << 4;
 #pragma unroll
-        for (int j = 0; j < N1 / 32; ++j) {
+        for (int j = 0; j < L::NTL2; ++j) {
           const u32x4 b = *reinterpret_cast<const u32x4 *>(lds + w1rd + j * 32 * 128 + sl);
           acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc2[j], 0, 0, 0);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    // ---- t1 of the tile: relu(acc2 + bias1) -> bf16, whole 128-byte row segments ----
+    // ---- t1 of the tile: relu(acc2 + bias1) -> bf16, whole 128-byte row segments (this wave's N1 / CH columns) ----
     const __amdgpu_buffer_rsrc_t rsrcT1 = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char *>(p.t1) + (size_t)clip * clip_rows * (N1 * 2), 0, (int)(clip_rows * (N1 * 2)), 0x00020000);
 #pragma unroll
-    for (int jh = 0; jh < N1 / 64; ++jh) {
-      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias1_l + jh * 64 + c8 * 8);
-      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias1_l + jh * 64 + c8 * 8 + 4);
+    for (int jh = 0; jh < L::NTL2 / 2; ++jh) {
+      const int col0 = wh * (N1 / CH) + jh * 64;
+      const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias1_l + col0 + c8 * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias1_l + col0 + c8 * 8 + 4);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Cs[(4 * half + r) * 68 + j * 32 + l31] = acc2[2 * jh + j][4 * q + r];
+          for (int r = 0; r < 4; ++r) Cw[(4 * half + r) * 68 + j * 32 + l31] = acc2[2 * jh + j][4 * q + r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8);
-        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cs + r8l * 68 + c8 * 8 + 4);
+        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cw + r8l * 68 + c8 * 8);
+        const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cw + r8l * 68 + c8 * 8 + 4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const float v[8] = {c0[0] + b0[0], c0[1] + b0[1], c0[2] + b0[2], c0[3] + b0[3],
                             c1[0] + b1[0], c1[1] + b1[1], c1[2] + b1[2], c1[3] + b1[3]};
         u32x4 o;
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) o[w2] = pack_bf16(fmaxf(v[2 * w2], 0.f), fmaxf(v[2 * w2 + 1], 0.f));
-        const unsigned off = ((evoff[q] - (unsigned)(c8 * 16)) >> L::LOG_C_N1) + (unsigned)(c8 * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcT1, (int)(off | einv[q]), p0 * n1b + jh * 128, 0);
+        // row 32 rg + 8 q + r8l of the tile (all 32 rows of the group: the pair splits t1 by COLUMNS)
+        const int row = 32 * rg + 8 * q + r8l, t = row >> lpx, px = row & (PX - 1);
+        const unsigned off = (unsigned)((t * HW + px) * (N1 * 2) + c8 * 16), inv = p0 + px < HW ? 0u : kInvalid;
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcT1, (int)(off | inv), p0 * n1b + col0 * 2, 0);
       }
     }
     clip = nclip;
@@ -316,30 +380,54 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the dead tail stages (zeros) land before the workgroup leaves its LDS
 }
 
+// Instantiations: (K3, C, N1) = (128, 512, 128) layer2.k -> layer2.k+1 with CH = 1 (tiles of 256 rows); (128, 512, 256)
+// layer2.3 -> layer3.0 and (256, 1024, 256) layer3.k -> layer3.k+1 with CH = 2 (wave pairs, tiles of 128 rows).
+static int conv31_rows(const Conv31Params &p) {
+  if (p.K3 == 128 && p.C == 512 && p.N1 == 128) return 256;
+  if ((p.K3 == 128 && p.C == 512 && p.N1 == 256) || (p.K3 == 256 && p.C == 1024 && p.N1 == 256)) return 128;
+  return 0;
+}
+
 bool conv31_valid(const Conv31Params &p) {
-  if (!(p.K3 == 128 && p.C == 512 && p.N1 == 128)) return false;            // instantiated: layer2's non-first blocks
-  if (p.n_clips <= 0 || p.HW <= 0 || p.T <= 0 || 256 % p.T != 0 || 256 / p.T < 8) return false;
+  const int m = conv31_rows(p);
+  if (m == 0) return false;
+  if (p.n_clips <= 0 || p.HW <= 0 || p.T <= 0 || m % p.T != 0 || m / p.T < 8) return false;
   if (p.fold != 0 && (p.fold % 64 != 0 || 2 * p.fold > p.C)) return false;  // a 64-channel chunk is shifted as a whole
   return (double)p.T * p.HW * p.C * 2.0 < 2.0e9;                             // 32-bit offsets inside a clip's block
+}
+
+template <int K3, int C, int N1, int CH>
+static hipError_t launch_c31(const Conv31Params &p, long ntiles, int n_cu, hipStream_t s) {
+  constexpr size_t kLdsBytes = C31<K3, C, N1, CH>::kBytes;
+  const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(512);
+  hipLaunchKernelGGL((conv31_fused_kernel<K3, C, N1, CH>), grid, block, kLdsBytes, s, p);
+  return hipGetLastError();
 }
 
 hipError_t launch_conv31_fused(const Conv31Params &p_in, hipStream_t s) {
   Conv31Params p = p_in;
   if (!p.t2 || !p.w3 || !p.bias3 || !p.res || !p.y || !p.w1 || !p.bias1 || !p.t1 || !conv31_valid(p)) return hipErrorInvalidValue;
-  const int px = 256 / p.T;
+  const int px = conv31_rows(p) / p.T;
   p.log_px = 0;
   while ((1 << p.log_px) < px) ++p.log_px;
   const DeviceInfo &di = device_info();
   if (di.status != hipSuccess) return di.status;
   const long ntiles = (long)p.n_clips * ((p.HW + px - 1) / px);
-  const dim3 grid((unsigned)(ntiles < di.n_cu ? ntiles : di.n_cu)), block(512);
-  constexpr size_t kLdsBytes = C31<128, 512, 128>::kBytes;
-  hipLaunchKernelGGL((conv31_fused_kernel<128, 512, 128>), grid, block, kLdsBytes, s, p);
-  return hipGetLastError();
+  if (p.K3 == 128 && p.N1 == 128) return launch_c31<128, 512, 128, 1>(p, ntiles, di.n_cu, s);
+  if (p.K3 == 128) return launch_c31<128, 512, 256, 2>(p, ntiles, di.n_cu, s);
+  return launch_c31<256, 1024, 256, 2>(p, ntiles, di.n_cu, s);
 }
 
 hipError_t opt_in_conv31() {
-  return lds_opt_in(reinterpret_cast<const void *>(&conv31_fused_kernel<128, 512, 128>), C31<128, 512, 128>::kBytes);
+  hipError_t first = hipSuccess;
+  auto opt_in = [&](const void *fn, size_t bytes) {
+    const hipError_t st = lds_opt_in(fn, bytes);
+    if (st != hipSuccess && first == hipSuccess) first = st;
+  };
+  opt_in(reinterpret_cast<const void *>(&conv31_fused_kernel<128, 512, 128, 1>), C31<128, 512, 128, 1>::kBytes);
+  opt_in(reinterpret_cast<const void *>(&conv31_fused_kernel<128, 512, 256, 2>), C31<128, 512, 256, 2>::kBytes);
+  opt_in(reinterpret_cast<const void *>(&conv31_fused_kernel<256, 1024, 256, 2>), C31<256, 1024, 256, 2>::kBytes);
+  return first;
 }
 
 }  // namespace tsm

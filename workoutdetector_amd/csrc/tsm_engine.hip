@@ -583,12 +583,12 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       p3.w = blk.d_wf; p3.bias = blk.d_bf; p3.Kp = blk.kpf; p3.K1 = c3.kp; p3.kseg_len = blk.ksegf;
       p3.x2 = x; p3.C2 = cd.cp; p3.Hi2 = hh; p3.Wi2 = ww; p3.stride2 = blk.stride;
     }
-    // conv3 + residual of this block and shift + conv1 of the NEXT block as one launch (bf16, no downsample branch on either
-    // side of the boundary geometry-wise: the next block keeps this block's frame size): bit 0x1000 of conv3's tile code
+    // conv3 + residual of this block and shift + conv1 of the NEXT block as one launch (bf16; this block without a downsample
+    // branch -- the next one may be the first of a stage: its conv1 is a stride-1 1x1 on this block's output either way):
+    // bit 0x1000 of conv3's tile code
     // (set by the tuning pass at the head of the next block), or forced / forbidden through TSM_FUSE_C3C1
     bool did31 = false;
-    if (prec == tsm::kPrecBf16 && !fused && blk.down < 0 && k + 1 < e->blocks.size() && e->fuse31 != 0 &&
-        e->blocks[k + 1].stride == 1 && e->blocks[k + 1].down < 0) {
+    if (prec == tsm::kPrecBf16 && !fused && blk.down < 0 && k + 1 < e->blocks.size() && e->fuse31 != 0) {
       const ConvLayer &c1n = e->convs[e->blocks[k + 1].conv1];
       tsm::Conv31Params q = make_p31(p3, c1n, t1, nn, ho * wo);
       if (tsm::conv31_valid(q)) {
