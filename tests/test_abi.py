@@ -35,6 +35,17 @@ def test_header_symbols_are_exported(lib):
         assert getattr(lib, sym) is not None
 
 
+def test_no_kernel_stub_is_missing_from_the_library():
+    """A kernel whose HOST stub was dropped at compile time (seen with hipcc 7.2: a template-dependent constant inside the
+    scalar-offset argument of a buffer builtin in a lambda -- no diagnostic, the object simply lacks the stub and its device
+    code) leaves an undefined tsm:: symbol that only fails at the first launch: refuse it here, on the CPU."""
+    from workoutdetector_amd.build import LIB_PATH, build_library
+    build_library()
+    out = subprocess.run(['nm', '-D', '--undefined-only', '-C', LIB_PATH], capture_output=True, text=True, check=True).stdout
+    missing = [ln for ln in out.splitlines() if 'tsm::' in ln]
+    assert not missing, missing
+
+
 def test_abi_version_and_config_layout(lib):
     from workoutdetector_amd import _lib
     assert lib.tsm_abi_version() == _lib.ABI_VERSION == 6

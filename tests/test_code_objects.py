@@ -114,3 +114,58 @@ def test_whole_bottleneck_kernel_budget(md):
             assert r['.max_flat_workgroup_size'] == 256 and r['.vgpr_count'] <= 512 and r['.agpr_count'] >= 160
             assert r['.private_segment_fixed_size'] == 0 and r['.vgpr_spill_count'] == 0
             assert codeobj.workgroups_per_cu(r, lds) == 1
+
+
+def test_cross_block_kernel_budget_and_wait_tables(md):
+    """conv31_fused_kernel: 8 waves = two per SIMD -> at most 256 registers, NO scratch (a spill would be a vector-memory
+    operation its counted waits know nothing about); the dynamic LDS of every instantiation fits one workgroup per CU.  And
+    the wait tables of csrc/tsm_conv31.hip (C31::wait_w3 / wait_w1 / wait_res: how many younger vector-memory operations may
+    stay in flight) restated here and checked against a brute-force simulation of the kernel's issue order."""
+    for args, lds in (('128, 512, 128, 1', 151168), ('128, 512, 256, 2', 105000), ('256, 1024, 256, 2', 123000)):
+        r = _one(md, f'conv31_fused_kernel<{args}>')
+        assert r['.max_flat_workgroup_size'] == 512 and r['.vgpr_count'] <= 256
+        assert r['.private_segment_fixed_size'] == 0 and r['.vgpr_spill_count'] == 0
+        assert codeobj.workgroups_per_cu(r, lds) == 1
+
+    def simulate(NC, NQ, NW1, NW3, AF, NT1S, PT2, STAGE, RD):
+        ops = []
+        for t in range(3):
+            for c in range(NC):
+                ops += [(t, c, 'W1', i) for i in range(NW1)] + [(t, c, 'W3', i) for i in range(NW3)]
+                if c == NC - 1:
+                    ops += [(t, c, 'AF', i) for i in range(AF)]
+                for q in range(NQ):
+                    ops += [(t, c, 'st', q), (t, c, 'ld', q)]
+                if STAGE and c < NC // 2:
+                    ops += [(t, c, 'T2', i) for i in range(PT2)]
+                if c == NC - 1:
+                    ops += [(t, c, 'T1', i) for i in range(NT1S)]
+        at = {o: i for i, o in enumerate(ops)}
+        out = {}
+        for c in range(NC):
+            pt, pc = (1, c - 1) if c > 0 else (0, NC - 1)
+            w3 = at[(1, c, 'W1', 0)] - 1 - at[(pt, pc, 'W3', NW3 - 1)]
+            end = at[(1, c, 'T2', PT2 - 1)] if (STAGE and c < NC // 2) else at[(1, c, 'ld', NQ - 1)]
+            w1 = end - at[(1, c, 'W1', NW1 - 1)]
+            res = {at[(1, c, 'st', q)] - 1 - at[divmod(NC + c - RD, NC) + ('ld', q)] for q in range(NQ)}
+            assert len(res) == 1
+            out[c] = (w3, w1, res.pop())
+        return out
+
+    def table(NC, NQ, NW1, NW3, AF, NT1S, PT2, STAGE, RD):
+        P = lambda c: PT2 if (STAGE and c < NC // 2) else 0                                     # noqa: E731
+        tot = lambda c: NW1 + NW3 + 2 * NQ + P(c) + (AF + NT1S if c == NC - 1 else 0)          # noqa: E731
+        out = {}
+        for nc in range(NC):
+            c0 = (nc - RD + NC) % NC
+            n = 2 * (NQ - 1) + P(c0) + (NT1S if c0 == NC - 1 else 0) + NW1 + NW3 + (AF if nc == NC - 1 else 0)
+            n += sum(tot((c0 + k) % NC) for k in range(1, RD))
+            out[nc] = (AF + 2 * NQ + NT1S if nc == 0 else 2 * NQ + P(nc - 1), NW3 + (AF if nc == NC - 1 else 0) + 2 * NQ + P(nc), n)
+        return out
+
+    for cfg in (dict(NC=8, NQ=4, NW1=2, NW3=2, AF=0, NT1S=8, PT2=2, STAGE=True, RD=1),        # <128, 512, 128, 1>
+                dict(NC=8, NQ=2, NW1=4, NW3=2, AF=8, NT1S=8, PT2=0, STAGE=False, RD=2),       # <128, 512, 256, 2>
+                dict(NC=16, NQ=2, NW1=4, NW3=4, AF=16, NT1S=8, PT2=0, STAGE=False, RD=2)):    # <256, 1024, 256, 2>
+        got = table(**cfg)
+        assert got == simulate(**cfg), cfg
+        assert max(max(v) for v in got.values()) < 64           # vmcnt is a 6-bit field

@@ -31,7 +31,8 @@ namespace tsm {
 //   * after the last chunk: t1 = relu(acc + bias1) -> bf16 -> stored ([256][N1], conv2 of block b + 1 reads it).
 // HBM bytes per tile row: K3*2 (t2) + C*2 (residual) + C*2 (y) + N1*2 (t1) against + C*2 more for the two launches it
 // replaces; the weights (C*K3 + N1*C elements per tile) stream from L2.  Three barriers per chunk; every vector-memory
-// wait is a counted vmcnt over the fixed issue order of a chunk
+// wait is a counted vmcnt (a running count of issued operations against the count at the awaited operation's issue) over
+// the issue order of a chunk
 //     [W1 chunk: NW1 DMA | W3 next chunk: NW3 DMA | CH = 2, last chunk: the next tile's A fragments |
 //      (store y, load next residual) x 4 / CH | CH = 1: t2 of the next tile, P DMA],
 // never vmcnt(0) inside the loop: the residual stream, the weight stream and the next tile's t2 stay in flight under
@@ -50,6 +51,8 @@ template <int K3, int C, int N1, int CH> struct C31 {
   static constexpr int NTL1 = 2 / CH;              // GEMM1 N-tiles per wave (of the chunk's two)
   static constexpr int NTL2 = N1 / 32 / CH;        // GEMM2 N-tiles per wave
   static constexpr int NQ = 4 / CH;                // 8-row epilogue steps per wave and chunk
+  static constexpr int RD = CH;                    // chunks the residual is requested ahead: a tile of 128 rows turns a chunk over in
+                                                   // less than an HBM round trip, so CH = 2 keeps TWO chunks of residual in flight
   static constexpr int RB3 = K3 * 2;               // bytes per row of t2 / of W3
   static constexpr int LPR3 = RB3 / 16;            // lanes (16-byte slots) per such row
   static constexpr int RPP3 = 1024 / RB3;          // rows per 1-KiB DMA piece
@@ -70,11 +73,35 @@ template <int K3, int C, int N1, int CH> struct C31 {
   static constexpr int kBias1 = kBias3 + C * 4;
   static constexpr int kZero = kBias1 + N1 * 4;
   static constexpr int kBytes = kZero + 128;
+  // ---- counted waits: vector-memory operations of a wave, in issue order, per chunk c of a tile:
+  //   W1(c) [NW1] | W3(c + 1) [NW3] | c last: the next tile's A fragments [AF] | (store y, load the residual of chunk c + RD) x NQ |
+  //   t2 pieces of the next tile [P(c)] | c last: the tile's t1 stores [NT1S]
+  // A wait names how many operations YOUNGER than the awaited one may stay in flight (they retire in order).
+  static constexpr int P(int c) { return (STAGE && c < NC / 2) ? PT2 : 0; }
+  static constexpr int tot(int c) { return NW1 + NW3 + 2 * NQ + P(c) + (c == NC - 1 ? AF + NT1S : 0); }
+  // W3's chunk nc (issued in chunk nc - 1, behind that chunk's W1): the rest of that chunk
+  static constexpr int wait_w3(int nc) { return nc == 0 ? AF + 2 * NQ + NT1S : 2 * NQ + P(nc - 1); }
+  // W1's chunk nc (issued at the head of chunk nc): the rest of this chunk up to GEMM2
+  static constexpr int wait_w1(int nc) { return NW3 + (nc == NC - 1 ? AF : 0) + 2 * NQ + P(nc); }
+  // the residual of a step of chunk nc (issued at the same step of chunk nc - RD, behind its store): the rest of that chunk,
+  // RD - 1 whole chunks, and this chunk up to the step -- the same number for every step
+  static constexpr int wait_res(int nc) {
+    const int c0 = (nc - RD + NC) % NC;
+    int n = 2 * (NQ - 1) + P(c0) + (c0 == NC - 1 ? NT1S : 0) + NW1 + NW3 + (nc == NC - 1 ? AF : 0);
+    for (int k = 1; k < RD; ++k) n += tot((c0 + k) % NC);
+    return n;
+  }
   static_assert(CH == 1 || CH == 2, "a wave, or a pair of waves, per 32 tile rows");
   static_assert(C / N1 == 4 || C / N1 == 2, "t1's row offsets are derived from y's by a shift");
   static_assert(!STAGE || (PT2 * NC == 2 * NT2 && PT2 >= 1 && NC >= 4), "the t2 pieces of the next tile ride on the first half of the chunks");
+  static_assert(NC % RD == 0, "the chunk loop is unrolled by the residual depth");
   static_assert(kBytes <= 160 * 1024, "LDS budget");
 };
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_imm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 __device__ __forceinline__ void wait_vmcnt_any(int n) {
 #define TSM_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
@@ -134,8 +161,14 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
     ybase[1] = t + 1 < T ? (unsigned)(L::kY + rp * 128) : (unsigned)L::kZero;   yflip[1] = t + 1 < T ? (unsigned)((rp >> 1) & 7) : 0u;
     ybase[2] = t > 0 ? (unsigned)(L::kY + rm * 128) : (unsigned)L::kZero;       yflip[2] = t > 0 ? (unsigned)((rm >> 1) & 7) : 0u;
   }
-  const unsigned w1rd = (unsigned)(L::kW1 + (wh * (N1 / CH) + l31) * 128), w1flip = (unsigned)((l31 >> 1) & 7);
-  const unsigned w3rd = (unsigned)(L::kW3 + (wh * (64 / CH) + l31) * L::RB3), rflip = (unsigned)(l31 & 15);
+  // fragment reads: row * row bytes + ((2 g + half) ^ flip) * 16 = (base ^ (g << 5)) with base = row * row bytes +
+  // ((half ^ flip & 1) << 4) + ((flip >> 1) << 5) -- the row starts are multiples of 128 / 256 / 512, so bits 5.. of the
+  // base hold nothing but the flip
+  const unsigned w1flip = (unsigned)((l31 >> 1) & 7), rflip = (unsigned)(l31 & 15);
+  const unsigned w1a = (unsigned)(L::kW1 + (wh * (N1 / CH) + l31) * 128) + (((unsigned)half ^ (w1flip & 1u)) << 4) + ((w1flip >> 1) << 5);
+  const unsigned w3a = (unsigned)(L::kW3 + (wh * (64 / CH) + l31) * L::RB3) + (((unsigned)half ^ (rflip & 1u)) << 4) + ((rflip >> 1) << 5);
+  static_assert(L::kW3 % 512 == 0 && L::kW1 % 128 == 0 && L::kY % 128 == 0 && L::kZero % 128 == 0 && L::kT2 % 512 == 0,
+                "XOR addressing of the fragment reads");
   const unsigned t2rd = (unsigned)(L::kT2 + arow * L::RB3);
   // direct A-fragment loads (CH = 2): 16 bytes of row `arow`, k16 group g at + 32 g
   const unsigned afoff = (unsigned)(((arow >> lpx) * HW + (arow & (PX - 1))) * L::RB3 + half * 16), afpx = (unsigned)(arow & (PX - 1));
@@ -171,11 +204,9 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW3, (lds_void *)(lds + L::kW3 + (wave * L::NW3 + i) * 1024), 16,
                                                (int)(w3off[i] | dead), nc * 64 * rb3, 0, 0);
   };
-  auto issue_w1 = [&](int nc) {
-#pragma unroll
-    for (int i = 0; i < L::NW1; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW1, (lds_void *)(lds + L::kW1 + (wave * L::NW1 + i) * 1024), 16,
-                                               (int)w1off[i], nc * 128, 0, 0);
+  auto issue_w1_piece = [&](int nc, int i) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW1, (lds_void *)(lds + L::kW1 + (wave * L::NW1 + i) * 1024), 16,
+                                             (int)w1off[i], nc * 128, 0, 0);
   };
   // STAGE: pieces i0 .. i0 + n - 1 of the t2 tile (clip, p0) into the staging buffer
   auto issue_t2 = [&](int clip, int p0, int i0, int n, unsigned dead) {
@@ -199,12 +230,13 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
     for (int g = 0; g < L::KT1; ++g)
       afr[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(afoff | inv | dead), p0 * rb3 + g * 32, 0);
   };
-  u32x4 rres[L::NQ];
-  auto load_res = [&](int q, int clip, int p0, int nc, unsigned dead) {
+  // the residual of a chunk's epilogue steps, requested RD chunks ahead (register set = chunk index mod RD)
+  u32x4 rres[L::RD * L::NQ];
+  auto load_res = [&](int slot, int q, int clip, int p0, int nc, unsigned dead) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.res) + (size_t)clip * clip_rows * (C * 2)), 0, (int)(clip_rows * (C * 2)), 0x00020000);
     const unsigned inv = (unsigned)p0 + epx[q] < (unsigned)HW ? 0u : kInvalid;
-    rres[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(evoff[q] | inv | dead), p0 * cb + nc * 128, 0);
+    rres[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(evoff[q] | inv | dead), p0 * cb + nc * 128, 0);
   };
 
   // ---- prologue: the first tile's t2, the first chunk of W3, the first chunk's residual ----------------------------
@@ -214,7 +246,9 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
   else load_afr(clip, p0, 0u);
   issue_w3(0, 0u);
 #pragma unroll
-  for (int q = 0; q < L::NQ; ++q) load_res(q, clip, p0, 0, 0u);
+  for (int r = 0; r < L::RD; ++r)
+#pragma unroll
+    for (int q = 0; q < L::NQ; ++q) load_res(r * L::NQ + q, q, clip, p0, r, 0u);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -251,29 +285,45 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
 #pragma unroll
     for (int q = 0; q < L::NQ; ++q) einv[q] = (unsigned)p0 + epx[q] < (unsigned)HW ? 0u : kInvalid;
 
-    for (int nc = 0; nc < L::NC; ++nc) {
-      // vector-memory operations of this wave that are younger than the ones awaited below (see the issue order above)
+    for (int nc0 = 0; nc0 < L::NC; nc0 += L::RD) {
+#pragma unroll
+     for (int rset = 0; rset < L::RD; ++rset) {
+      const int nc = nc0 + rset;
       const bool last = nc + 1 == L::NC;
       const int pnow = nc < L::NC / 2 ? L::PT2 : 0;                        // t2 pieces of the next tile issued in this chunk
-      const int pprev = (nc > 0 && nc - 1 < L::NC / 2) ? L::PT2 : 0;       // ... in the previous one (chunk NC - 1 of the previous tile: none)
-      const int tail = (nc == 0 && s > 0) ? L::NT1S : 0;                   // the previous tile's t1 stores
-      const int afprev = (nc == 0 && s > 0) ? L::AF : 0;                   // ... and this tile's A-fragment loads, issued in its last chunk
-      wait_vmcnt_any(2 * L::NQ + pprev + tail + afprev);                   // W3's chunk nc has landed (this wave's pieces)
+      // W3's chunk nc has landed (this wave's pieces)
+      if (nc == 0) wait_vmcnt_imm<L::wait_w3(0)>();
+      else if (nc - 1 < L::NC / 2) wait_vmcnt_imm<L::wait_w3(1)>();
+      else wait_vmcnt_imm<L::wait_w3(L::NC - 1)>();
       __builtin_amdgcn_s_barrier();                                        // A: ... everybody's; GEMM2 of chunk nc - 1 is over
-      issue_w1(nc);
+#pragma unroll
+      for (int i = 0; i < L::NW1; ++i) issue_w1_piece(nc, i);
       // ---- GEMM1: y[rows of this row group][this wave's channels of the chunk] ----
       f32x16 acc1[L::NTL1];
 #pragma unroll
       for (int j = 0; j < L::NTL1; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
+      {
+        // B fragments through a ring of four, read four MFMAs ahead (left to the compiler the loop was read-two / wait /
+        // multiply-two).  Fragment (g, j) sits at (ba ^ (g << 5)) + j * 32 rows: the row's XOR swizzle as ONE v_xor per read
+        // instead of KT1 precomputed address registers.
+        unsigned ba = w3a;
+        asm volatile("" : "+v"(ba));                       // (keeps the KT1 addresses from being hoisted out of the chunk loop)
+        constexpr int NM = L::KT1 * L::NTL1, D = 4;
+        u32x4 ring[D];
 #pragma unroll
-      for (int g = 0; g < L::KT1; ++g) {
-        const unsigned sl = ((2 * g + half) ^ rflip) << 4;
+        for (int m = 0; m < D; ++m)
+          ring[m] = *reinterpret_cast<const u32x4 *>(lds + (ba ^ (unsigned)((m / L::NTL1) << 5)) + (m % L::NTL1) * 32 * L::RB3);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < L::NTL1; ++j) {
-          const u32x4 b = *reinterpret_cast<const u32x4 *>(lds + w3rd + j * 32 * L::RB3 + sl);
-          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[g]), __builtin_bit_cast(bf16x8, b), acc1[j], 0, 0, 0);
+        for (int m = 0; m < NM; ++m) {
+          const u32x4 b = ring[m % D];
+          if (m + D < NM)
+            ring[m % D] = *reinterpret_cast<const u32x4 *>(lds + (ba ^ (unsigned)(((m + D) / L::NTL1) << 5)) + ((m + D) % L::NTL1) * 32 * L::RB3);
+          acc1[m % L::NTL1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[m / L::NTL1]), __builtin_bit_cast(bf16x8, b),
+                                                                      acc1[m % L::NTL1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise sinks the reads back next to their MFMA)
         }
       }
       if constexpr (!L::STAGE) {    // the pair's slab: this wave's 32 columns of all 32 rows, complete behind barrier B
@@ -306,26 +356,35 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
           c1 = *reinterpret_cast<const f32x4 *>(Cs + (16 * wh + 8 * q + r8l) * 68 + c8 * 8 + 4);
         }
         // this step's residual (requested one chunk ago)
-        wait_vmcnt_any(2 * (L::NQ - 1) + pprev + tail + L::NW1 + L::NW3 + (last ? L::AF : 0));
+        // this step's residual (requested RD chunks ago); the values differ where the window crosses the tile's end
+        static_assert(L::RD <= 2 && (L::STAGE ? L::RD == 1 : L::wait_res(2) == L::wait_res(L::NC - 2)), "the cases below");
+        if (nc == 0) wait_vmcnt_imm<L::wait_res(0)>();
+        else if (nc == 1) wait_vmcnt_imm<L::wait_res(1)>();
+        else if (last) wait_vmcnt_imm<L::wait_res(L::NC - 1)>();
+        else if (L::STAGE && nc - 1 < L::NC / 2) wait_vmcnt_imm<L::wait_res(2)>();
+        else wait_vmcnt_imm<L::wait_res(L::NC - 2)>();
         // (pins the residual's first use behind the counted wait: the scheduler otherwise hoists its bf16 -> fp32 unpacking into
         //  GEMM1's MFMA shadow, and the compiler's own wait for these registers then sits in front of GEMM1)
-        asm volatile("" : "+v"(rres[q]));
+        asm volatile("" : "+v"(rres[rset * L::NQ + q]));
         float v[8] = {c0[0] + bias0[0], c0[1] + bias0[1], c0[2] + bias0[2], c0[3] + bias0[3],
                       c1[0] + bias1[0], c1[1] + bias1[1], c1[2] + bias1[2], c1[3] + bias1[3]};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += split_elem(rres[q], e);
+        for (int e = 0; e < 8; ++e) v[e] += split_elem(rres[rset * L::NQ + q], e);
         u32x4 o;
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) o[w2] = pack_bf16(fmaxf(v[2 * w2], 0.f), fmaxf(v[2 * w2 + 1], 0.f));
         __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(evoff[q] | einv[q]), p0 * cb + nc * 128, 0);
         *reinterpret_cast<u32x4 *>(lds + yw[q]) = o;
-        if (last) load_res(q, nclip, np0, 0, next_dead);
-        else load_res(q, clip, p0, nc + 1, 0u);
+        if (nc + L::RD < L::NC) load_res(rset * L::NQ + q, q, clip, p0, nc + L::RD, 0u);
+        else load_res(rset * L::NQ + q, q, nclip, np0, nc + L::RD - L::NC, next_dead);
       }
       if constexpr (L::STAGE) {
         if (pnow > 0) issue_t2(nclip, np0, L::PT2 * nc, L::PT2, next_dead);
       }
-      wait_vmcnt_any(L::NW3 + (last ? L::AF : 0) + 2 * L::NQ + pnow);      // W1's chunk nc has landed (this wave's pieces)
+      // W1's chunk nc has landed (this wave's pieces)
+      if (last) wait_vmcnt_imm<L::wait_w1(L::NC - 1)>();
+      else if (nc < L::NC / 2) wait_vmcnt_imm<L::wait_w1(0)>();
+      else wait_vmcnt_imm<L::wait_w1(L::NC - 2)>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // ... and this wave's rows of the LDS tile are written
       __builtin_amdgcn_s_barrier();                                        // C
       // ---- GEMM2: t1 += shift(y chunk) * W1[:, chunk]^T ----
@@ -333,17 +392,31 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
       const int sel = c0ch < p.fold ? 1 : (c0ch < 2 * p.fold ? 2 : 0);     // wave-uniform: frames t + 1 / t - 1 / t
       const unsigned yb = sel == 1 ? ybase[1] : sel == 2 ? ybase[2] : ybase[0];
       const unsigned yf = sel == 1 ? yflip[1] : sel == 2 ? yflip[2] : yflip[0];
+      {
+        // the four A fragments up front, the B fragments through a ring of four (see GEMM1)
+        unsigned ya = yb + (((unsigned)half ^ (yf & 1u)) << 4) + ((yf >> 1) << 5), bb = w1a;
+        asm volatile("" : "+v"(ya), "+v"(bb));
+        u32x4 a4[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const u32x4 a = *reinterpret_cast<const u32x4 *>(lds + yb + (((2 * g + half) ^ yf) << 4));
-        const unsigned sl = ((2 * g + half) ^ w1flip) << 4;
+        for (int g = 0; g < 4; ++g) a4[g] = *reinterpret_cast<const u32x4 *>(lds + (ya ^ (unsigned)(g << 5)));
+        constexpr int NM = 4 * L::NTL2, D = 4;
+        u32x4 ring[D];
 #pragma unroll
-        for (int j = 0; j < L::NTL2; ++j) {
-          const u32x4 b = *reinterpret_cast<const u32x4 *>(lds + w1rd + j * 32 * 128 + sl);
-          acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc2[j], 0, 0, 0);
+        for (int m = 0; m < D; ++m)
+          ring[m] = *reinterpret_cast<const u32x4 *>(lds + (bb ^ (unsigned)((m / L::NTL2) << 5)) + (m % L::NTL2) * 32 * 128);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          const u32x4 b = ring[m % D];
+          if (m + D < NM)
+            ring[m % D] = *reinterpret_cast<const u32x4 *>(lds + (bb ^ (unsigned)(((m + D) / L::NTL2) << 5)) + ((m + D) % L::NTL2) * 32 * 128);
+          acc2[m % L::NTL2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4[m / L::NTL2]), __builtin_bit_cast(bf16x8, b),
+                                                                      acc2[m % L::NTL2], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+     }
     }
     // ---- t1 of the tile: relu(acc2 + bias1) -> bf16, whole 128-byte row segments (this wave's N1 / CH columns) ----
     const __amdgpu_buffer_rsrc_t rsrcT1 = __builtin_amdgcn_make_buffer_rsrc(
