@@ -56,21 +56,26 @@ def main(path, frames=256, size=224):
         return r
 
     take(['conv1'])
-    for li, nb in enumerate((3, 4, 6, 3), 1):
-        for b in range(nb):
-            p = f'layer{li}.{b}'
+    blocks = [f'layer{li}.{b}' for li, nb in enumerate((3, 4, 6, 3), 1) for b in range(nb)]
+    have_t1 = False       # the previous block's conv3 launch (conv31_fused_kernel) ran this block's shift + conv1 as well
+    for k, p in enumerate(blocks):
+        if True:
+            b = int(p.split('.')[1])
             separate_down = b == 0 and n_down == 0
-            first = next(it, None)
-            if first is None:
-                break
-            if 'bneck_ws' in first['Kernel_Name']:      # the whole Bottleneck in one launch
-                rows.append((p + ' (block)', [p + '.conv1', p + '.conv2', p + '.conv3'] + ([p + '.downsample'] if b == 0 else []), first))
-                continue
-            if separate_down:
-                rows.append((p + '.downsample', [p + '.downsample'], first))
-                take([p + '.conv1'])
+            if have_t1:
+                have_t1 = False
             else:
-                rows.append((p + '.conv1', [p + '.conv1'], first))
+                first = next(it, None)
+                if first is None:
+                    break
+                if 'bneck_ws' in first['Kernel_Name']:      # the whole Bottleneck in one launch
+                    rows.append((p + ' (block)', [p + '.conv1', p + '.conv2', p + '.conv3'] + ([p + '.downsample'] if b == 0 else []), first))
+                    continue
+                if separate_down:
+                    rows.append((p + '.downsample', [p + '.downsample'], first))
+                    take([p + '.conv1'])
+                else:
+                    rows.append((p + '.conv1', [p + '.conv1'], first))
             nxt = next(it, None)
             if nxt is None:
                 break
@@ -78,7 +83,11 @@ def main(path, frames=256, size=224):
                 rows.append((p + '.conv2+conv3', [p + '.conv2', p + '.conv3'], nxt))
                 continue
             rows.append((p + '.conv2', [p + '.conv2'], nxt))
-            take([p + '.conv3'] + ([p + '.downsample'] if (b == 0 and not separate_down) else []))
+            r3 = take([p + '.conv3'] + ([p + '.downsample'] if (b == 0 and not separate_down) else []))
+            if r3 is not None and 'conv31_fused' in r3['Kernel_Name'] and k + 1 < len(blocks):
+                # conv3 + residual of this block and shift + conv1 of the next one in ONE launch: priced with both
+                rows[-1] = (p + '.conv3+' + blocks[k + 1] + '.conv1', rows[-1][1] + [blocks[k + 1] + '.conv1'], r3)
+                have_t1 = True
     if next(it, None) is not None or len(rows) != len(convs):
         print('launch count', len(convs), 'does not match the expected schedule: rows below may be misaligned')
     tot = totf = 0.0
@@ -88,10 +97,10 @@ def main(path, frames=256, size=224):
         tot += dur
         totf += fl
         kn = r['Kernel_Name'].split('<')[1].split('>')[0] if '<' in r['Kernel_Name'] else r['Kernel_Name'][:30]
-        if any(k in r['Kernel_Name'] for k in ('conv23_fused', 'conv_bf16_256', 'conv3x3_ws', 'conv1x1_ws', 'bneck_ws')):
+        if any(k in r['Kernel_Name'] for k in ('conv23_fused', 'conv_bf16_256', 'conv3x3_ws', 'conv1x1_ws', 'bneck_ws', 'conv31_fused')):
             kn = r['Kernel_Name'].split('tsm::')[1].split('(')[0]
         grid = int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))
-        print(f"{nm:26s} {kn:44s} wgs={grid:6d} {dur:8.1f}us {fl / dur / 1e6:7.1f} TF/s  vgpr={r.get('VGPR_Count','?')}")
+        print(f"{nm:34s} {kn:44s} wgs={grid:6d} {dur:8.1f}us {fl / dur / 1e6:7.1f} TF/s  vgpr={r.get('VGPR_Count','?')}")
     span = (int(fw[-1]['End_Timestamp']) - int(fw[0]['Start_Timestamp'])) / 1e3
     print(f'sum conv {tot:.1f} us = {totf / tot / 1e6:.1f} TF/s; forward span {span:.1f} us; '
           f'other kernels {sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in fw if "conv" not in r["Kernel_Name"] and "stem_" not in r["Kernel_Name"] and "bneck_ws" not in r["Kernel_Name"] and "splitk_reduce" not in r["Kernel_Name"]):.1f} us')

@@ -8,6 +8,6 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc ${PMC:-GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CU_CYCLES} \
   --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq_$tag -o run -- \
-  python3 $R/bench.py --steps 2 --warmup 2 --no-alt --no-cpu-baseline "$@" > $R/gpurun_out/pmc_sq_$tag.log 2>&1
+  python3 $R/bench.py --steps 2 --warmup 2 --no-alt --no-cpu-baseline --no-parity "$@" > $R/gpurun_out/pmc_sq_$tag.log 2>&1
 cd $R
 python3 tools/pmc_summary.py gpurun_out/pmc_sq_$tag/run_counter_collection.csv gpurun_out/pmc_sq_$tag/run_kernel_trace.csv > gpurun_out/pmc_sq_$tag.txt

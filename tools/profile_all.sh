@@ -11,7 +11,7 @@ O=$R/gpurun_out
 run_stats() {  # name, frames, size, bench args...
   local name=$1 frames=$2 size=$3; shift 3
   (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_${name}_stats -o run -- \
-     python3 $R/bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline "$@" > $O/${tag}_${name}_bench_line.json 2> $O/${tag}_${name}_stats.log)
+     python3 $R/bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline --no-parity "$@" > $O/${tag}_${name}_bench_line.json 2> $O/${tag}_${name}_stats.log)
   python3 tools/layer_times.py $O/${tag}_${name}_stats/run_kernel_trace.csv $frames $size > $O/${tag}_${name}_per_layer.txt
   cp $O/${tag}_${name}_stats/run_kernel_stats.csv $O/${tag}_${name}_kernel_stats.csv
   tail -1 $O/${tag}_${name}_per_layer.txt
