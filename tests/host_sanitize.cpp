@@ -37,16 +37,16 @@ static void fuzz_tune_lines(unsigned seed, int rounds) {
   // a parser that dropped such a line would make every rank of a multi-GPU job tune for itself again)
   {
     std::vector<int> codes(5, -1);
-    const std::string line = want + "2054,1030,6,3075,3\n";
+    const std::string line = want + "2054,1030,6,3075,4102\n";       // (4102 = 6 | 0x1000: conv3 also runs the next block's conv1)
     EXPECT(parse_tune_line(line.c_str(), want, kNumTiles, &codes));
-    EXPECT(codes[0] == (6 | 0x800) && codes[1] == (6 | 0x400) && codes[2] == 6 && codes[3] == (3 | 0x400 | 0x800) && codes[4] == 3);
+    EXPECT(codes[0] == (6 | 0x800) && codes[1] == (6 | 0x400) && codes[2] == 6 && codes[3] == (3 | 0x400 | 0x800) && codes[4] == (6 | 0x1000));
   }
   const char *bad[] = {"", "\n", "|", "abi3", "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|",
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3",            // too few
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,3,3",        // too many
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,9",          // tile out of range
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,35",         // reserved bits set
-                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,4099",       // a bit above the fusion bits
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,8195",       // a bit above the fusion bits
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,-1",
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,99999999999999999999999999",
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,,3,3,3",
@@ -74,7 +74,7 @@ static void fuzz_tune_lines(unsigned seed, int rounds) {
     if (line.size() > 4000) line.resize(4000);
     std::vector<int> codes(5, -7);
     const bool ok = parse_tune_line(line.c_str(), want, kNumTiles, &codes);
-    for (int c : codes) EXPECT(ok ? (c >= 0 && (c & ~0xD0F) == 0 && (c & 15) < kNumTiles) : c == -7);
+    for (int c : codes) EXPECT(ok ? (c >= 0 && (c & ~0x1D0F) == 0 && (c & 15) < kNumTiles) : c == -7);
   }
 }
 

@@ -372,7 +372,7 @@ def test_tune_cache_file_round_trip(hip_lib, sd0, tmp_path, monkeypatch):
 
 def test_tune_cache_keeps_the_fusion_bits(hip_lib, sd0, tmp_path, monkeypatch):
     """A cached line whose codes carry the fusion bits (+1024: conv2 + conv3 as one launch, +2048: the whole block as one
-    launch) must be READ BACK, not rejected: the ranks of a multi-GPU job share one tune cache (rank 0 tunes, the others
+    launch, +4096: conv3 also runs the next block's conv1) must be READ BACK, not rejected: the ranks of a multi-GPU job share one tune cache (rank 0 tunes, the others
     read), and a parser that dropped such lines would make every rank tune for itself.  A bf16 engine at a batch where the
     tuner picks the whole-block kernel writes its line; the line is then edited (every layer1 / layer2 fusion bit the
     layer supports is set or cleared by hand) and a second engine must report exactly the edited codes."""
