@@ -84,10 +84,12 @@ def test_weight_stationary_kernels_own_a_whole_register_file(md):
     """One wave per SIMD, up to 512 unified registers each (weights pinned in the accumulation half), no scratch; the
     dynamic LDS they are launched with (csrc constants, static_assert'ed <= 160 KiB at compile time) leaves exactly one
     workgroup per CU."""
-    for name, lds in (('conv3x3_ws_kernel<false>', 2 * 46 * 1024), ('conv3x3_ws_kernel<true>', 162048),
-                      ('conv3x3_ws128_kernel', 150000), ('conv1x1_wsn_kernel<512, 256, false>', 2 * 65536 + 1024)):
+    # (accumulation registers: the pinned weights only -- since round 4 these files are built with MFMA results in
+    #  architectural VGPRs, build.EXTRA_FLAGS, so the accumulators no longer count here)
+    for name, lds, agprs in (('conv3x3_ws_kernel<false>', 2 * 46 * 1024, 200), ('conv3x3_ws_kernel<true>', 162048, 200),
+                             ('conv3x3_ws128_kernel', 150000, 200), ('conv1x1_wsn_kernel<512, 256, false>', 2 * 65536 + 1024, 160)):
         r = _one(md, name)
-        assert r['.max_flat_workgroup_size'] == 256 and r['.vgpr_count'] <= 512 and r['.agpr_count'] >= 200
+        assert r['.max_flat_workgroup_size'] == 256 and r['.vgpr_count'] <= 512 and r['.agpr_count'] >= agprs
         assert r['.private_segment_fixed_size'] == 0
         assert codeobj.workgroups_per_cu(r, lds) == 1, name
     assert _one(md, 'conv3x3_ws_kernel<true>')['.vgpr_count'] <= 512
@@ -112,6 +114,7 @@ def test_whole_bottleneck_kernel_budget(md):
         for shift in ('true', 'false'):
             r = _one(md, f'bneck_ws_kernel<{cin}, {shift}>')
             assert r['.max_flat_workgroup_size'] == 256 and r['.vgpr_count'] <= 512 and r['.agpr_count'] >= 160
+            assert r['.vgpr_count'] - r['.agpr_count'] <= 256        # architectural VGPRs incl. the MFMA results (vgpr-form build)
             assert r['.private_segment_fixed_size'] == 0 and r['.vgpr_spill_count'] == 0
             assert codeobj.workgroups_per_cu(r, lds) == 1
 

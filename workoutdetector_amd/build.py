@@ -24,6 +24,13 @@ LIB_PATH = os.environ.get('TSM_LIB_PATH') or os.path.join(PKG_DIR, 'libtsm_hip.s
 SOURCES = ['tsm_igemm.hip', 'tsm_bf16_256.hip', 'tsm_ws.hip', 'tsm_bneck.hip', 'tsm_conv31.hip', 'tsm_fused23.hip',
            'tsm_stem.hip', 'tsm_ops.hip', 'tsm_engine.hip']
 OBJ_DIR = os.path.join(CSRC, 'obj')
+# Per-file compiler options.  tsm_bneck.hip: MFMA results in architectural VGPRs (the "vgprcd" form).  Its kernels pin 208
+# weight registers in the accumulation half of the file, and with AGPRs in use the compiler otherwise puts EVERY MFMA
+# result there too -- 168 v_accvgpr_read per step and wave (18 % of the step's vector-ALU instructions, on a kernel that is
+# bound by exactly those) just to hand accumulators to the epilogues; the option leaves the weights where they are pinned.
+# tsm_ws.hip: the same for the weight-stationary kernels (884 -> 16 v_accvgpr_read in the file; their epilogues run from
+# registers).
+EXTRA_FLAGS = {'tsm_bneck.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'tsm_ws.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 ARCH = 'gfx950'
 
 
@@ -82,7 +89,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header) \
             or src == 'tsm_engine.hip'
         if stale:
-            cmd = base + ([f'-DTSM_BUILD_ID="{csrc_sha16()}"'] if src == 'tsm_engine.hip' else []) + ['-c', path, '-o', obj]
+            cmd = base + EXTRA_FLAGS.get(src, []) + ([f'-DTSM_BUILD_ID="{csrc_sha16()}"'] if src == 'tsm_engine.hip' else []) + \
+                ['-c', path, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
