@@ -56,6 +56,7 @@ def csrc_sha16() -> str:
     for name in sorted(os.listdir(CSRC)):
         if name.endswith(('.hip', '.h')):
             h.update(name.encode())
+            h.update(' '.join(EXTRA_FLAGS.get(name, [])).encode())      # per-file compiler options change the code object too
             with open(os.path.join(CSRC, name), 'rb') as f:
                 h.update(f.read())
     return h.hexdigest()[:16]
