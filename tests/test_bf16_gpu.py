@@ -240,6 +240,40 @@ def test_weight_stationary_3x3_equals_the_igemm_tiles_bitwise(hip_lib, monkeypat
         assert_bf16_op(_nchw(outs['ws']).numpy(), want.numpy(), what='ws bf16')
 
 
+@pytest.mark.parametrize('n,hi,wi,relu', [
+    (16, 64, 64, True),      # layer2.0.conv2 at the config-5 size: 32 x 32 outputs, 8 x 8 tiles (17 x 17 patch: the one-pixel tenth DMA round), 256 tiles
+    (80, 64, 64, True),      # 1280 tiles: five per workgroup, both accumulator sets end a workgroup's run
+    (48, 64, 64, True),      # 768 tiles: three per workgroup (odd count: the other set ends the run)
+    (8, 56, 56, True),       # at 224^2: 28 x 28 outputs, 4 x 14 tiles on 16 lanes per row
+    (3, 23, 18, False),      # odd input sizes (the last output column's right tap is padding), ragged tiles, no ReLU
+    (5, 7, 5, True),         # a frame smaller than one tile
+    (2, 33, 31, True),       # 17 x 16 outputs
+    (1, 3, 200, True),       # one tile row, 100 outputs across
+    (2, 130, 9, True),       # narrow and tall: tiles of 5 columns on 8 lanes per row
+    (300, 8, 8, True),       # more frames than workgroups: 4 x 4 outputs
+    (4, 16, 96, True),       # tiles wider than 32 outputs cannot hold two rows: geometry search over all lane layouts
+])
+def test_weight_stationary_3x3_stride2_equals_the_igemm_tiles_bitwise(hip_lib, monkeypatch, n, hi, wi, relu):
+    """conv3x3_ws128_kernel<true> (layer2.0's conv2: stride 2, 128 -> 128 channels; the patch stored with de-interleaved
+    columns, one M-tile pair per tile, the accumulator sets alternating between tiles) against conv_igemm's bf16 tiles
+    through the per-op entry point: same bits; and against the oracle at the bf16 mode's tolerance."""
+    from workoutdetector_amd.engine import conv_bn_act_nhwc
+    g = torch.Generator().manual_seed(9300 + n + hi + wi)
+    x = torch.randn(n, 128, hi, wi, generator=g)
+    w = torch.randn(128, 128, 3, 3, generator=g) * (2.0 / (9 * 128)) ** 0.5
+    bn = _bn(128, g)
+    outs = {}
+    for tile in ('ws', '128x128', '64x64'):
+        monkeypatch.setenv('TSM_CONV_TILE', tile)
+        outs[tile] = conv_bn_act_nhwc(_nhwc(x).cuda(), w.cuda(), *[b.cuda() for b in bn], stride=2, relu=relu, dtype='bf16').cpu()
+    assert outs['ws'].shape == (n, (hi - 1) // 2 + 1, (wi - 1) // 2 + 1, 128)
+    assert torch.equal(outs['64x64'], outs['128x128'])
+    assert torch.equal(outs['ws'], outs['64x64'])
+    if n * hi * wi <= 70000:
+        want = tsm_oracle.conv_bn_act_bf16(x, w, bn, 2, 1, relu, None)
+        assert_bf16_op(_nchw(outs['ws']).numpy(), want.numpy(), what='ws stride 2 bf16')
+
+
 @pytest.mark.parametrize('cin,n,hi,wi,shiftT,relu', [
     (256, 16, 64, 64, 16, True),   # layer1.1 / 1.2 conv1 at the config-5 size (one clip): 512 tiles, shift over 16 frames
     (256, 32, 56, 56, 8, True),    # at 224^2, four clips: 784 tiles (3 per workgroup), tiles straddle frames (3136 rows per frame)

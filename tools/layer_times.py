@@ -21,21 +21,9 @@ def read_rows(path):
                  LDS=l) for n, s, e, g, w, v, l in db.execute(q)]
 
 
-def main(path, frames=256, size=224):
-    rows = read_rows(path)
-    rows.sort(key=lambda r: int(r['Start_Timestamp']))
-    names = [r['Kernel_Name'] for r in rows]
-    idx = [i for i, n in enumerate(names) if 'pack_input' in n]
-    fw = rows[idx[-2]:idx[-1]]
-    # a split-K layer is two launches: the conv and its splitk_reduce, whose time is added to the conv's row
-    convs = []
-    for r in fw:
-        if 'conv' in r['Kernel_Name'] or 'stem_' in r['Kernel_Name'] or 'bneck_ws' in r['Kernel_Name']:   # stem_direct / stem_pool = conv1 (+ max-pool); bneck_ws = a whole block
-            convs.append(dict(r))
-        elif 'splitk_reduce' in r['Kernel_Name'] and convs:
-            convs[-1]['End_Timestamp'] = int(convs[-1]['End_Timestamp']) + int(r['End_Timestamp']) - int(r['Start_Timestamp'])
-            convs[-1]['Kernel_Name'] = convs[-1]['Kernel_Name'].replace('>', ' +reduce>', 1)
-    byname = {r['name']: r for r in layer_table(size, size)}
+def match_schedule(convs):
+    """[(label, [layer names priced with it], launch record)] for the conv-like launches of one forward, in launch order,
+    and whether the launch count matched the expected schedule."""
     # Expected launch order, consumed against the trace: the stem; per block [downsample,] conv1, then either conv2 and
     # conv3 (the latter fused with the downsample branch in a stage's first block) or ONE conv23_fused /
     # conv3x3_ws_kernel<true> launch.
@@ -88,7 +76,26 @@ def main(path, frames=256, size=224):
                 # conv3 + residual of this block and shift + conv1 of the next one in ONE launch: priced with both
                 rows[-1] = (p + '.conv3+' + blocks[k + 1] + '.conv1', rows[-1][1] + [blocks[k + 1] + '.conv1'], r3)
                 have_t1 = True
-    if next(it, None) is not None or len(rows) != len(convs):
+    return rows, not (next(it, None) is not None or len(rows) != len(convs))
+
+
+def main(path, frames=256, size=224):
+    rows = read_rows(path)
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    names = [r['Kernel_Name'] for r in rows]
+    idx = [i for i, n in enumerate(names) if 'pack_input' in n]
+    fw = rows[idx[-2]:idx[-1]]
+    # a split-K layer is two launches: the conv and its splitk_reduce, whose time is added to the conv's row
+    convs = []
+    for r in fw:
+        if 'conv' in r['Kernel_Name'] or 'stem_' in r['Kernel_Name'] or 'bneck_ws' in r['Kernel_Name']:   # stem_direct / stem_pool = conv1 (+ max-pool); bneck_ws = a whole block
+            convs.append(dict(r))
+        elif 'splitk_reduce' in r['Kernel_Name'] and convs:
+            convs[-1]['End_Timestamp'] = int(convs[-1]['End_Timestamp']) + int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+            convs[-1]['Kernel_Name'] = convs[-1]['Kernel_Name'].replace('>', ' +reduce>', 1)
+    byname = {r['name']: r for r in layer_table(size, size)}
+    rows, ok = match_schedule(convs)
+    if not ok:
         print('launch count', len(convs), 'does not match the expected schedule: rows below may be misaligned')
     tot = totf = 0.0
     for nm, parts, r in rows:

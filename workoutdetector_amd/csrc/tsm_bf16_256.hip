@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256_kernel(const ConvParams 
 #pragma unroll
       for (int w2 = 0; w2 < 4; ++w2) o[w2] = pack_bf16(fmaxf(v[2 * w2], floor_), fmaxf(v[2 * w2 + 1], floor_));
       const int row = wm * 128 + i * 32 + rr;
-      __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (row * p.Cout + n0 + wn * 64 + c8 * 8) * 2, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (row * p.Cout + n0 + wn * 64 + c8 * 8) * 2, 0, TSM_AUX_256);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slab reads done before the next slab overwrites it
   }
@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq) {
             const u32x4 ov = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
-            __builtin_amdgcn_raw_buffer_store_b128(ov, rsrcY, o, j * 64 + qq * 16, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rsrcY, o, j * 64 + qq * 16, TSM_AUX_256);
           }
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
         u32x4 o;
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) o[w2] = pack_bf16(fmaxf(v[2 * w2], floor_), fmaxf(v[2 * w2 + 1], floor_));
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, ((wm * 128 + t * 8 + r8l) * p.Cout + cur.n0 + wn * 64 + c8 * 8) * 2, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, ((wm * 128 + t * 8 + r8l) * p.Cout + cur.n0 + wn * 64 + c8 * 8) * 2, 0, TSM_AUX_256);
         if (t + 8 < 16) load_res(cur, t + 8, t & 7);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slab reads done before the next sub-slab overwrites it
       }

@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq) {
             const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
-            __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)yo, itl * 64 + qq * 16, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)yo, itl * 64 + qq * 16, TSM_AUX_BNECK);
           }
         }
       });

@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
         u32x4 o;
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) o[w2] = pack_bf16(fmaxf(v[2 * w2], 0.f), fmaxf(v[2 * w2 + 1], 0.f));
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(evoff[q] | einv[q]), p0 * cb + nc * 128, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(evoff[q] | einv[q]), p0 * cb + nc * 128, TSM_AUX_C31);
         *reinterpret_cast<u32x4 *>(lds + yw[q]) = o;
         if (nc + L::RD < L::NC) load_res(rset * L::NQ + q, q, clip, p0, nc + L::RD, 0u);
         else load_res(rset * L::NQ + q, q, nclip, np0, nc + L::RD - L::NC, next_dead);
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
         // row 32 rg + 8 q + r8l of the tile (all 32 rows of the group: the pair splits t1 by COLUMNS)
         const int row = 32 * rg + 8 * q + r8l, t = row >> lpx, px = row & (PX - 1);
         const unsigned off = (unsigned)((t * HW + px) * (N1 * 2) + c8 * 16), inv = p0 + px < HW ? 0u : kInvalid;
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcT1, (int)(off | inv), p0 * n1b + col0 * 2, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcT1, (int)(off | inv), p0 * n1b + col0 * 2, TSM_AUX_C31);
       }
     }
     clip = nclip;

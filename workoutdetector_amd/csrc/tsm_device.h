@@ -34,6 +34,24 @@ constexpr int kBK = 32;
 
 constexpr unsigned kInvalid = 0x80000000u;  // >= num_records of every descriptor below
 
+// Cache policy of the activation stores of the bf16 kernel families (the aux operand of raw_buffer_store: 0 = plain,
+// 2 = nt, 16 = sc1 = write-through that drops the line from the XCD's L2, MI355X_MICROARCH.md "stores of each flavour").
+#ifndef TSM_OUT_AUX
+#define TSM_OUT_AUX 0
+#endif
+#ifndef TSM_AUX_256
+#define TSM_AUX_256 TSM_OUT_AUX
+#endif
+#ifndef TSM_AUX_C31
+#define TSM_AUX_C31 TSM_OUT_AUX
+#endif
+#ifndef TSM_AUX_WS
+#define TSM_AUX_WS TSM_OUT_AUX
+#endif
+#ifndef TSM_AUX_BNECK
+#define TSM_AUX_BNECK TSM_OUT_AUX
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const WsParams p) {
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
         const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcYall, (int)(yoff + (unsigned)(nt * 64 + (2 * half + qq) * 16)), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcYall, (int)(yoff + (unsigned)(nt * 64 + (2 * half + qq) * 16)), 0, TSM_AUX_WS);
       }
     }
   };
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const WsParams p) {
           for (int qq = 0; qq < 2; ++qq) {
             const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
             __builtin_amdgcn_raw_buffer_store_b128(
-                o, rsrcY, (int)(yo[mt] == kInvalid ? kInvalid : yo[mt] + (unsigned)(it * 64 + (2 * half + qq) * 16)), 0, 0);
+                o, rsrcY, (int)(yo[mt] == kInvalid ? kInvalid : yo[mt] + (unsigned)(it * 64 + (2 * half + qq) * 16)), 0, TSM_AUX_WS);
           }
         }
         // schedule of this region: one W3 fragment read, then its two MFMAs, each followed by a share of the epilogue's
@@ -469,6 +469,15 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws_kernel(const WsParams p) {
 // LDS-DMA into one of two buffers of eight 32-byte planes (wave w fills planes 2 w, 2 w + 1), transposed MFMA, the
 // epilogue of a pair of M-tiles in ten pieces under the MFMA steps of the next pair, 16-byte groups stored from
 // registers (a wave writes its own 64-byte channel slice of each pixel).
+//
+// S2 = true: the same with stride 2 (layer2.0's conv2).  A tile of TR x TC <= 64 output pixels (ONE pair of M-tiles: a patch
+// is four times its outputs) reads a (2 TR + 1) x (2 TC + 1) patch of at most 17 x 17 = 289 pixels: nine whole DMA rounds of
+// 32 pixels per plane and a tenth of ONE pixel (lanes 0 and 1 only -- a whole round there would run 992 bytes into the next
+// plane), 2 x 73 984 B of LDS.  Two things keep the pixel-fragment reads conflict-free although neighbouring outputs are two
+// input columns apart: the patch is stored with its columns DE-INTERLEAVED (row pitch 2 TC + 1: the TC + 1 even columns,
+// then the TC odd ones; tap kx = 0 / 2 reads position c / c + 1 of the even run, kx = 1 position c of the odd run), and an
+// M-tile's lanes are laid out LPR = 8 / 16 / 32 lanes per tile row with, for LPR = 8, rows r and r + 4 in the same 16-lane
+// group (rows 2 (2 TC + 1) x 4 positions apart: an odd multiple of 8, i.e. the other 16-byte half of the same banks).
 // ---------------------------------------------------------------------------------------------
 constexpr int kW8Rounds = 6;                      // DMA rounds of 32 patch pixels per plane
 constexpr int kW8PatchMax = kW8Rounds * 32;       // 192 patch pixels (10 x 18 for an 8 x 16 tile, 6 x 30 for 4 x 28)
@@ -476,16 +485,49 @@ constexpr int kW8Plane = kW8PatchMax * 32;
 constexpr int kW8BufBytes = 8 * kW8Plane;         // 49 152 B
 constexpr int kW8LdsBytes = 2 * kW8BufBytes + 512;
 constexpr int kW8AgprFrags = 56;                  // fragments kept in accumulation registers
+constexpr int kS2PatchMax = 289;                  // 17 x 17 for an 8 x 8 tile (config 5: 32 x 32 outputs), 9 x 29 for 4 x 14 (28 x 28)
+constexpr int kS2Rounds = 10;                     // the tenth: one pixel
+constexpr int kS2Plane = kS2PatchMax * 32;        // 9 248 B
+constexpr int kS2BufBytes = 8 * kS2Plane;         // 73 984 B
+constexpr int kS2LdsBytes = 2 * kS2BufBytes + 512;
 
+// Stride 2: lanes per tile row of an M-tile pair (64 lanes), and the tile geometry for Ho x Wo outputs: TC <= LPR columns,
+// TR <= 64 / LPR rows, (2 TR + 1) x (2 TC + 1) <= kS2PatchMax patch pixels, fewest tiles per frame (ties: the smaller patch).
+static int ws_s2_lanes_per_row(int tc) { return tc <= 8 ? 8 : tc <= 16 ? 16 : tc <= 32 ? 32 : 64; }
+static bool ws_s2_tile_geometry(int Ho, int Wo, int *tr_out, int *tc_out) {
+  long best_tiles = -1;
+  int best_tr = 0, best_tc = 0, best_patch = 0;
+  for (int tc = 1; tc <= 64; ++tc) {
+    int tr = 64 / ws_s2_lanes_per_row(tc);
+    if (tr > Ho) tr = Ho;
+    if (tr < 1) continue;
+    const int patch = (2 * tr + 1) * (2 * tc + 1);
+    if (patch > kS2PatchMax) continue;
+    if (2 * tr * (2 * tc + 1) + ws_s2_lanes_per_row(tc) + tc > kS2PatchMax) continue;   // idle lanes of a row read behind it: inside the plane
+    const long tiles = (long)((Ho + tr - 1) / tr) * ((Wo + tc - 1) / tc);
+    if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && patch < best_patch)) {
+      best_tiles = tiles; best_tr = tr; best_tc = tc; best_patch = patch;
+    }
+  }
+  *tr_out = best_tr;
+  *tc_out = best_tc;
+  return best_tiles > 0;
+}
+
+template <bool S2>
 __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x kW8BufBytes | bias
+  constexpr int kRounds = S2 ? kS2Rounds : kW8Rounds, kPlane = S2 ? kS2Plane : kW8Plane, kBuf = 8 * kPlane;
+  constexpr int kMT = S2 ? 2 : 4;                  // M-tiles of a tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x kBuf | bias
   typedef __attribute__((address_space(3))) void lds_void;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
-  const int H = p.H, W = p.W, TR = p.tr, TC = p.tc, PW = TC + 2;
-  const int nr = ((TR + 2) * PW + 31) >> 5;
-  const int tiles_x = (W + TC - 1) / TC, tiles_y = (H + TR - 1) / TR, tiles_f = tiles_x * tiles_y;
+  const int H = p.H, W = p.W, TR = p.tr, TC = p.tc;            // (H, W: the INPUT frame)
+  const int Ho = S2 ? (H - 1) / 2 + 1 : H, Wo = S2 ? (W - 1) / 2 + 1 : W;
+  const int PW = S2 ? 2 * TC + 1 : TC + 2, PH = S2 ? 2 * TR + 1 : TR + 2;
+  const int nr = (PH * PW + 31) >> 5;
+  const int tiles_x = (Wo + TC - 1) / TC, tiles_y = (Ho + TR - 1) / TR, tiles_f = tiles_x * tiles_y;
   const int ntiles = p.N * tiles_f;
   const int frame_bytes = H * W * 256;
 
@@ -497,50 +539,62 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
     wr[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, ((wave * 32 + l31) * 1152 + s * 16 + half * 8) * 2, 0, 0);
 #pragma unroll
   for (int s = 0; s < kW8AgprFrags; ++s) asm volatile("" : "+a"(wr[s]));
-  float *bias_lds = reinterpret_cast<float *>(lds + 2 * kW8BufBytes);
+  float *bias_lds = reinterpret_cast<float *>(lds + 2 * kBuf);
   if (tid < 128) bias_lds[tid] = p.bias2[tid];
   const float floor_ = p.relu ? 0.f : -INFINITY;
 
-  // ---- loader: plane g holds bytes [32 g, 32 g + 32) of every patch pixel (halves swapped where (pixel >> 3) is odd);
-  // in round i this lane fills half (lane & 1) of patch pixel 32 i + (lane >> 1), in planes 2 wave and 2 wave + 1
+  // ---- loader: plane g holds bytes [32 g, 32 g + 32) of every patch position (halves swapped where (position >> 3) is
+  // odd); in round i this lane fills half (lane & 1) of position 32 i + (lane >> 1), in planes 2 wave and 2 wave + 1.
+  // Position -> patch pixel: row-major; S2: within a row the even columns first, then the odd ones.
   const int hsel = (lane & 1) ^ ((lane >> 4) & 1);
-  unsigned dslot[kW8Rounds];                       // (byte offset of the pixel relative to the patch origin) >> 4 | patch column << 24
+  unsigned dslot[kRounds];                         // (byte offset of the pixel relative to the patch origin) >> 4 | patch column << 24
 #pragma unroll
-  for (int i = 0; i < kW8Rounds; ++i) {
+  for (int i = 0; i < kRounds; ++i) {
     const int pidx = 32 * i + (lane >> 1);
-    const int pr = pidx / PW, pc = pidx - pr * PW;
+    const int pr = pidx / PW, q = pidx - pr * PW;
+    const int pc = S2 ? (q <= TC ? 2 * q : 2 * (q - TC - 1) + 1) : q;
     dslot[i] = (unsigned)((pr * W + pc) * 16) | ((unsigned)pc << 24);
   }
   auto issue_patch = [&](int t, int b) {
     const int f = t / tiles_f, rem = t - f * tiles_f;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-    const int x0 = tx * TC;
+    const int x0 = S2 ? 2 * tx * TC - 1 : tx * TC - 1, y0 = S2 ? 2 * ty * TR - 1 : ty * TR - 1;   // the patch origin
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)f * frame_bytes), 0, frame_bytes, 0x00020000);
-    const int tbase = ((ty * TR - 1) * W + (x0 - 1)) * 256 + (4 * wave + hsel) * 16;
-    unsigned char *dst = lds + b * kW8BufBytes + 2 * wave * kW8Plane;
+    const int tbase = (y0 * W + x0) * 256 + (4 * wave + hsel) * 16;
+    unsigned char *dst = lds + b * kBuf + 2 * wave * kPlane;
 #pragma unroll
-    for (int i = 0; i < kW8Rounds; ++i)
-      if (i < nr) {
-        const int xg = x0 - 1 + (int)(dslot[i] >> 24);
+    for (int i = 0; i < kRounds; ++i)
+      if (i < nr && (!S2 || i < kS2Rounds - 1 || lane < 2)) {       // (S2's tenth round: position 288 alone)
+        const int xg = x0 + (int)(dslot[i] >> 24);
         const unsigned off = (unsigned)tbase + ((dslot[i] & 0xFFFFFFu) << 4);
         const unsigned o = (unsigned)xg < (unsigned)W ? off : kInvalid;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(dst + i * 1024), 16, (int)o, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(dst + kW8Plane + i * 1024), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(dst + kPlane + i * 1024), 16,
                                                  (int)(o == kInvalid ? kInvalid : o + 32u), 0, 0, 0);
       }
   };
 
-  // ---- this lane's pixel in each of the four M-tiles (shared by all waves)
-  int prow[4], pcol[4], pp0[4];
+  // ---- this lane's pixel in each of the M-tiles (shared by all waves)
+  int prow[kMT], pcol[kMT], pp0[kMT];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
+  for (int mt = 0; mt < kMT; ++mt) {
     const int q = mt * 32 + l31;
-    const bool ok = q < TR * TC;
-    const int r = q / TC, c = q - r * TC;
-    prow[mt] = ok ? r : 0x4000;
-    pcol[mt] = c;
-    pp0[mt] = ok ? r * PW + c : 0;
+    if constexpr (S2) {
+      const int lpr = TC <= 8 ? 8 : TC <= 16 ? 16 : TC <= 32 ? 32 : 64;
+      const int j = q / lpr, c = q - j * lpr;
+      const int r = lpr == 8 ? (j >> 1) + 4 * (j & 1) : j;         // LPR = 8: rows r, r + 4 share a 16-lane group
+      const bool ok = r < TR && c < TC;
+      prow[mt] = ok ? r : 0x4000;
+      pcol[mt] = c;
+      pp0[mt] = (r < TR ? 2 * r * PW : 0) + c;                      // (idle lanes read inside the plane, next to their row's pixels)
+    } else {
+      const bool ok = q < TR * TC;
+      const int r = q / TC, c = q - r * TC;
+      prow[mt] = ok ? r : 0x4000;
+      pcol[mt] = c;
+      pp0[mt] = ok ? r * PW + c : 0;
+    }
   }
   const __amdgpu_buffer_rsrc_t rsrcYall = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((size_t)p.M * 256), 0x00020000);
 
@@ -566,7 +620,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
       for (int qq = 0; qq < 2; ++qq) {
         const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
         __builtin_amdgcn_raw_buffer_store_b128(
-            o, rsrcYall, (int)(yoff[m] == kInvalid ? kInvalid : yoff[m] + (unsigned)(wave * 64 + (2 * half + qq) * 16)), 0, 0);
+            o, rsrcYall, (int)(yoff[m] == kInvalid ? kInvalid : yoff[m] + (unsigned)(wave * 64 + (2 * half + qq) * 16)), 0, TSM_AUX_WS);
       }
     }
   };
@@ -574,7 +628,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
     const int f = tt / tiles_f, rem = tt - f * tiles_f;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int oy = ty * TR + prow[mt], ox = tx * TC + pcol[mt];
-    return (oy < H && ox < W) ? (unsigned)(((f * H + oy) * W + ox) * 256) : kInvalid;
+    return (oy < Ho && ox < Wo) ? (unsigned)(((f * Ho + oy) * Wo + ox) * 256) : kInvalid;
   };
 
   // A pair of M-tiles (2 mp, 2 mp + 1): 72 steps (tap, g) of two pixel-fragment reads (two steps ahead) and two MFMAs
@@ -587,10 +641,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         if (g == 0) {
-          const int pp = pp0[2 * mp + m] + ky * PW + kx;
+          const int pp = pp0[2 * mp + m] + ky * PW + (S2 ? (kx == 1 ? TC + 1 : kx >> 1) : kx);
           tb[m] = (unsigned)(pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4));
         }
-        px[s & 3][m] = *reinterpret_cast<const u32x4 *>(buf + tb[m] + g * kW8Plane);
+        px[s & 3][m] = *reinterpret_cast<const u32x4 *>(buf + tb[m] + g * kPlane);
       }
     };
 #pragma unroll
@@ -619,27 +673,67 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
   int t = blockIdx.x, nb = 0;
   if (t < ntiles) issue_patch(p.reverse ? ntiles - 1 - t : t, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  for (; t < ntiles; t += gridDim.x, nb ^= 1) {
-    __builtin_amdgcn_s_barrier();      // every wave's share of this patch has landed; nobody still reads the other buffer
-    const int tn = t + gridDim.x;
-    if (tn < ntiles) issue_patch(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
-    const int tt = p.reverse ? ntiles - 1 - t : t;
-    const unsigned char *buf = lds + nb * kW8BufBytes;
-    mpair(buf, 0, accA, accB, offB);                                    // (B = M-tiles 2, 3 of the previous tile)
-    offA[0] = out_off(tt, 0); offA[1] = out_off(tt, 1);
-    mpair(buf, 1, accB, accA, offA);
-    offB[0] = out_off(tt, 2); offB[1] = out_off(tt, 3);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                    // the next patch is older than this iteration's eight stores
-  }
+  if constexpr (S2) {
+    // one pair per tile: the accumulator sets alternate from tile to tile (the epilogue of tile i rides on tile i + 1)
+    auto step = [&](f32x16 (&cur)[2], const f32x16 (&prev)[2], const unsigned (&prev_off)[2], unsigned (&cur_off)[2]) {
+      __builtin_amdgcn_s_barrier();    // every wave's share of this patch has landed; nobody still reads the other buffer
+      const int tn = t + gridDim.x;
+      if (tn < ntiles) issue_patch(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
+      const int tt = p.reverse ? ntiles - 1 - t : t;
+      mpair(lds + nb * kBuf, 0, cur, prev, prev_off);
+      cur_off[0] = out_off(tt, 0); cur_off[1] = out_off(tt, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                  // the next patch is older than this tile's four stores
+      t = tn;
+      nb ^= 1;
+    };
+    for (;;) {
+      step(accA, accB, offB, offA);
+      if (t >= ntiles) {
 #pragma unroll
-  for (int k = 0; k < 10; ++k) epi_piece(accB, k, offB);
+        for (int k = 0; k < 10; ++k) epi_piece(accA, k, offA);
+        break;
+      }
+      step(accB, accA, offA, offB);
+      if (t >= ntiles) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) epi_piece(accB, k, offB);
+        break;
+      }
+    }
+  } else {
+    for (; t < ntiles; t += gridDim.x, nb ^= 1) {
+      __builtin_amdgcn_s_barrier();      // every wave's share of this patch has landed; nobody still reads the other buffer
+      const int tn = t + gridDim.x;
+      if (tn < ntiles) issue_patch(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
+      const int tt = p.reverse ? ntiles - 1 - t : t;
+      const unsigned char *buf = lds + nb * kBuf;
+      mpair(buf, 0, accA, accB, offB);                                    // (B = M-tiles 2, 3 of the previous tile)
+      offA[0] = out_off(tt, 0); offA[1] = out_off(tt, 1);
+      mpair(buf, 1, accB, accA, offA);
+      offB[0] = out_off(tt, 2); offB[1] = out_off(tt, 3);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                    // the next patch is older than this iteration's eight stores
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) epi_piece(accB, k, offB);
+  }
+}
+
+static bool conv3x3_ws128_common(const ConvParams &p) {
+  return p.prec == kPrecBf16 && p.C == 128 && p.Cout == 128 && p.Kp == 1152 && p.pad == 1 && !p.res && !p.x2 && p.T == 0 &&
+         p.kseg_len == 0 && (double)p.M * 256.0 < 2.0e9 && (double)p.Hi * p.Wi * 256.0 < 2.0e9;
+}
+
+// stride 2 (layer2.0's conv2)
+static bool conv3x3_ws128s2_valid(const ConvParams &p) {
+  int tr, tc;
+  return conv3x3_ws128_common(p) && p.stride == 2 && p.Ho == (p.Hi - 1) / 2 + 1 && p.Wo == (p.Wi - 1) / 2 + 1 && p.Wi <= 2048 &&
+         ws_s2_tile_geometry(p.Ho, p.Wo, &tr, &tc);
 }
 
 bool conv3x3_ws128_valid(const ConvParams &p) {
   int tr, tc;
-  return p.prec == kPrecBf16 && p.C == 128 && p.Cout == 128 && p.Kp == 1152 && p.stride == 1 && p.pad == 1 && p.Hi == p.Ho &&
-         p.Wi == p.Wo && !p.res && !p.x2 && p.T == 0 && p.kseg_len == 0 && (double)p.M * 256.0 < 2.0e9 &&
-         ws_tile_geometry(p.Hi, p.Wi, &tr, &tc, 128, kW8PatchMax);
+  if (conv3x3_ws128s2_valid(p)) return true;
+  return conv3x3_ws128_common(p) && p.stride == 1 && p.Hi == p.Ho && p.Wi == p.Wo && ws_tile_geometry(p.Hi, p.Wi, &tr, &tc, 128, kW8PatchMax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -770,7 +864,7 @@ __global__ void __launch_bounds__(256, 1) conv1x1_ws_kernel(const Ws1Params p) {
       for (int qq = 0; qq < 2; ++qq) {
         const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
         __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(yoff == kInvalid ? kInvalid : yoff + (unsigned)(nt * 64 + (2 * half + qq) * 16)),
-                                               0, 0);
+                                               0, TSM_AUX_WS);
       }
     }
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the next tile is older than this tile's four stores
@@ -932,7 +1026,7 @@ __global__ void __launch_bounds__(256, 1) conv1x1_wsn_kernel(const WsnParams p) 
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
           const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
-          __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(yoff + (unsigned)(ch0 * 2 + (2 * half + qq) * 16)), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(yoff + (unsigned)(ch0 * 2 + (2 * half + qq) * 16)), 0, TSM_AUX_WS);
         }
       }
     }
@@ -963,6 +1057,17 @@ bool conv3x3_ws_valid(const ConvParams &p) {
 static int ws_grid_setup() { return device_info().n_cu; }
 
 hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
+  if (conv3x3_ws128s2_valid(p)) {
+    WsParams q{};
+    q.x = p.x; q.w2 = p.w; q.bias2 = p.bias; q.y = p.y;
+    q.N = p.N; q.H = p.Hi; q.W = p.Wi; q.M = p.M; q.relu = p.relu; q.reverse = p.reverse;
+    ws_s2_tile_geometry(p.Ho, p.Wo, &q.tr, &q.tc);
+    const long ntiles = (long)q.N * ((p.Ho + q.tr - 1) / q.tr) * ((p.Wo + q.tc - 1) / q.tc);
+    const int n_cu = ws_grid_setup();
+    if (device_info().status != hipSuccess) return device_info().status;
+    hipLaunchKernelGGL(conv3x3_ws128_kernel<true>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kS2LdsBytes, s, q);
+    return hipGetLastError();
+  }
   if (conv3x3_ws128_valid(p)) {
     WsParams q{};
     q.x = p.x; q.w2 = p.w; q.bias2 = p.bias; q.y = p.y;
@@ -971,7 +1076,7 @@ hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
     const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
     const int n_cu = ws_grid_setup();
     if (device_info().status != hipSuccess) return device_info().status;
-    hipLaunchKernelGGL(conv3x3_ws128_kernel, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kW8LdsBytes, s, q);
+    hipLaunchKernelGGL(conv3x3_ws128_kernel<false>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kW8LdsBytes, s, q);
     return hipGetLastError();
   }
   if (!conv3x3_ws_valid(p)) return hipErrorInvalidValue;
@@ -1046,7 +1151,8 @@ hipError_t opt_in_ws() {
   };
   opt_in(reinterpret_cast<const void *>(&conv3x3_ws_kernel<false>), kWsLdsBytes);
   opt_in(reinterpret_cast<const void *>(&conv3x3_ws_kernel<true>), kWsLdsBytes3All);
-  opt_in(reinterpret_cast<const void *>(&conv3x3_ws128_kernel), kW8LdsBytes);
+  opt_in(reinterpret_cast<const void *>(&conv3x3_ws128_kernel<false>), kW8LdsBytes);
+  opt_in(reinterpret_cast<const void *>(&conv3x3_ws128_kernel<true>), kS2LdsBytes);
   opt_in(reinterpret_cast<const void *>(&conv1x1_ws_kernel<256>), 2 * 16 * 4096 + 256);
   opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<128, 256, true>), 2 * 65536 + 1024);
   opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<256, 128, false>), 2 * 65536 + 1024);
