@@ -18,22 +18,25 @@ from workoutdetector_amd.weights import make_state_dict  # noqa: E402
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 bad = 0
 # (channels, frames, h, w): tiles per workgroup from < 1 to several; ragged tiles; frames smaller than a tile
-for ch, n, h, w in [(64, 64, 64, 64), (64, 200, 64, 64), (64, 96, 56, 56), (64, 37, 23, 18), (64, 700, 8, 8),
-                    (128, 64, 32, 32), (128, 300, 32, 32), (128, 96, 28, 28), (128, 37, 23, 18), (128, 700, 8, 8)]:
+# (stride 2: conv3x3_ws128_kernel<true>, layer2.0's conv2 -- one M-tile pair per tile, the accumulator sets alternate)
+for ch, n, h, w, stride in [(64, 64, 64, 64, 1), (64, 200, 64, 64, 1), (64, 96, 56, 56, 1), (64, 37, 23, 18, 1), (64, 700, 8, 8, 1),
+                            (128, 64, 32, 32, 1), (128, 300, 32, 32, 1), (128, 96, 28, 28, 1), (128, 37, 23, 18, 1), (128, 700, 8, 8, 1),
+                            (128, 64, 64, 64, 2), (128, 112, 64, 64, 2), (128, 96, 56, 56, 2), (128, 37, 23, 18, 2), (128, 700, 8, 8, 2),
+                            (128, 11, 33, 200, 2)]:
     g = torch.Generator().manual_seed(n + ch)
     x = torch.randn(n, h, w, ch, generator=g).cuda()
     wt = (torch.randn(ch, ch, 3, 3, generator=g) * (2.0 / (9 * ch)) ** 0.5).cuda()
     bn = [torch.rand(ch, generator=g).cuda() + 0.5, torch.randn(ch, generator=g).cuda() * 0.1,
           torch.randn(ch, generator=g).cuda() * 0.1, torch.rand(ch, generator=g).cuda() + 0.5]
     os.environ['TSM_CONV_TILE'] = '64x64'
-    ref = conv_bn_act_nhwc(x, wt, *bn, stride=1, relu=True, dtype='bf16')
+    ref = conv_bn_act_nhwc(x, wt, *bn, stride=stride, relu=True, dtype='bf16')
     os.environ['TSM_CONV_TILE'] = 'ws'
     fails = 0
     for _ in range(REPS):
-        got = conv_bn_act_nhwc(x, wt, *bn, stride=1, relu=True, dtype='bf16')
+        got = conv_bn_act_nhwc(x, wt, *bn, stride=stride, relu=True, dtype='bf16')
         fails += int(not torch.equal(got, ref))
     bad += fails
-    print(f'per-op  ch={ch} n={n} {h}x{w}: {fails}/{REPS} runs differ from the 64x64 tile')
+    print(f'per-op  ch={ch} n={n} {h}x{w} stride {stride}: {fails}/{REPS} runs differ from the 64x64 tile')
 # conv1x1_ws_kernel / conv1x1_wsn_kernel (conv1 of layer1 / layer2 / layer3.0 with the fused temporal shift)
 for cin, cout, n, h, w, T in [(256, 64, 64, 64, 64, 16), (256, 64, 96, 56, 56, 8), (64, 64, 64, 64, 64, 16), (256, 64, 27, 7, 5, 3),
                                (64, 64, 700, 8, 8, 7), (256, 128, 64, 64, 64, 16), (512, 128, 96, 32, 32, 16), (512, 256, 96, 32, 32, 8),
