@@ -155,6 +155,24 @@ def test_fused_stem_maxpool_equals_separate_kernels_bitwise(hip_lib, sd0, monkey
     assert got['1'][0].shape == (16, (h // 2 + 1) // 2, (w // 2 + 1) // 2, 64)
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'bf16x3', 'f32'])
+@pytest.mark.parametrize('h,w,b', [(224, 224, 2), (256, 256, 3), (90, 70, 2), (91, 75, 2), (33, 47, 5), (64, 97, 2)])
+def test_stem_reading_the_reference_layout_equals_the_packed_input_bitwise(hip_lib, sd0, monkeypatch, dtype, h, w, b):
+    """The pool-fused stem fed with the reference layout itself ([N, T, 3, H, W] fp32: it rounds / splits while staging its
+    patch, no pack launch) against the same stem behind pack_input_kernel (TSM_STEM_PLANAR=0): the pooled 'stem' tap and
+    the logits agree bit for bit -- even and odd widths (an odd width ends a row in half a pixel pair), ragged tiles."""
+    from workoutdetector_amd.engine import TsmEngine
+    x = make_input(170 + h + w, b, 8, h, w)
+    got = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('TSM_STEM_PLANAR', flag)
+        eng = TsmEngine(height=h, width=w, max_clips=b, state_dict=sd0, dtype=dtype)
+        got[flag] = (eng.forward_tap(x, 'stem'), eng.run(None, {'input': x})[0])
+        eng.close()
+    assert np.array_equal(got['1'][0], got['0'][0]) and np.array_equal(got['1'][1], got['0'][1])
+    assert np.isfinite(got['1'][1]).all() and np.abs(got['1'][0]).max() > 0
+
+
 @pytest.mark.parametrize('n,hi,wi,cin,cout,k,stride,relu,shiftT,use_res', [
     (8, 16, 16, 256, 256, 3, 1, True, 0, False),   # layer3 conv2 at the config-5 size: 2048 rows = 8 full tiles
     (4, 16, 16, 256, 256, 3, 2, True, 0, False),   # stride 2 (layer3.0 / layer4.0 conv2): 256 rows

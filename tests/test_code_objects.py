@@ -99,9 +99,11 @@ def test_weight_stationary_kernels_own_a_whole_register_file(md):
 def test_stems_occupancy(md):
     """bf16 stem + max-pool: 77 760 B of LDS and <= 128 registers -> TWO 8-wave workgroups per CU; the
     split-bf16 and fp32 forms hold one (their 32-bit conv tile + weights need > 80 KB)."""
-    r = _one(md, 'stem_pool_kernel<false>')
-    assert r['.group_segment_fixed_size'] <= 80 * 1024 and r['.vgpr_count'] <= 128 and r['workgroups_per_cu'] == 2
-    for name in ('stem_pool_kernel<true>', 'stem_pool_f32_kernel'):
+    for name in ('stem_pool_kernel<false, false>', 'stem_pool_kernel<false, true>'):      # (<.., true>: reads [N, 3, H, W] fp32 itself)
+        r = _one(md, name)
+        assert r['.group_segment_fixed_size'] <= 80 * 1024 and r['.vgpr_count'] <= 128 and r['workgroups_per_cu'] == 2, name
+        assert r['.private_segment_fixed_size'] == 0, name
+    for name in ('stem_pool_kernel<true, false>', 'stem_pool_kernel<true, true>', 'stem_pool_f32_kernel<false>', 'stem_pool_f32_kernel<true>'):
         r = _one(md, name)
         assert r['.group_segment_fixed_size'] <= codeobj.LDS_PER_CU and r['.vgpr_count'] <= 256
         assert r['workgroups_per_cu'] == 1

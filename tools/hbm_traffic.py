@@ -29,10 +29,20 @@ def load(path, counter):
     return per, names
 
 
+def forward_starts(kernel_names):
+    """Indices of the first launch of every forward in a launch-ordered list of kernel names: the pack of an NTCHW input,
+    or -- since the pool-fused stem reads that layout itself -- a stem launch that no pack precedes."""
+    out = []
+    for i, n in enumerate(kernel_names):
+        if 'pack_input' in n or (('stem_pool' in n or 'stem_direct' in n) and (i == 0 or 'pack_input' not in kernel_names[i - 1])):
+            out.append(i)
+    return out
+
+
 def last_forward(per, names):
     ids = sorted(per)
-    packs = [d for d in ids if 'pack_input' in names[d]]
-    return [d for d in ids if packs[-2] <= d < packs[-1]]
+    starts = forward_starts([names[d] for d in ids])
+    return ids[starts[-2]:starts[-1]]
 
 
 def main(fetch_csv, write_csv, dominant='conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, true>'):

@@ -8,6 +8,8 @@ import os
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from workoutdetector_amd.flops import layer_table  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from hbm_traffic import forward_starts  # noqa: E402
 
 
 def read_rows(path):
@@ -83,7 +85,7 @@ def main(path, frames=256, size=224):
     rows = read_rows(path)
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     names = [r['Kernel_Name'] for r in rows]
-    idx = [i for i, n in enumerate(names) if 'pack_input' in n]
+    idx = forward_starts(names)
     fw = rows[idx[-2]:idx[-1]]
     # a split-K layer is two launches: the conv and its splitk_reduce, whose time is added to the conv's row
     convs = []

@@ -5,6 +5,10 @@
 import csv
 import sys
 from collections import defaultdict
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from hbm_traffic import forward_starts  # noqa: E402
 
 
 def main(cc_path, kt_path):
@@ -18,8 +22,8 @@ def main(cc_path, kt_path):
     for r in csv.DictReader(open(kt_path)):
         dur[int(r['Dispatch_Id'])] = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     ids = sorted(per)
-    packs = [d for d in ids if 'pack_input' in names[d]]
-    lo, hi = packs[-2], packs[-1]
+    starts = forward_starts([names[d] for d in ids])
+    lo, hi = ids[starts[-2]], ids[starts[-1]]
     cols = None
     for d in ids:
         if not (lo <= d < hi) or not ('conv' in names[d] or 'stem_' in names[d] or 'bneck' in names[d]):

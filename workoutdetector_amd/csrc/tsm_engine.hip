@@ -105,6 +105,7 @@ struct tsm_engine {
   bool fuse_down = true;  // TSM_FUSE_DOWNSAMPLE=0 runs the downsample branch as its own launch
   bool stem_pool = true;    // TSM_STEM_POOL=0: separate max-pool launch behind the direct stem
   bool stem_direct = true;  // TSM_STEM_DIRECT=0: bf16-format stems on the generic implicit-GEMM kernel (bit-identical, slower)
+  bool stem_planar = true;  // TSM_STEM_PLANAR=0: an NTCHW input is packed by its own launch first (bit-identical, one more pass over the input)
   // TSM_TUNE_CACHE=<file>: tuned tile codes are appended to / read from this file, one line per bucket, keyed by
   // `tune_sig` (ABI, device name, geometry, dtype): a later process skips the timing pass.  Codes never change
   // results and every code is re-validated against its layer at launch (run_forward, code_ok), so a stale, foreign
@@ -414,8 +415,17 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
 
   const int prec = e->prec;
   const float *in4 = e->d_in4;
-  if (layout >= TSM_LAYOUT_NTHWC4) {
-    in4 = d_clips;  // already packed by tsm_preprocess: consumed in place
+  // The pool-fused stem reads the reference layout ([N, T, 3, H, W] fp32) itself and converts while it stages its patch:
+  // no pack launch, no packed copy (TSM_STEM_PLANAR=0 and every other stem form keep the pack; all bit-identical).
+  const bool pool_stem = e->stem_direct && e->stem_pool && !want("conv1");
+  const bool planar = layout == TSM_LAYOUT_NTCHW && e->stem_planar && pool_stem && !want("input") &&
+                      (double)cfg.height * cfg.width * 12.0 < 2.0e9;
+  if (layout >= TSM_LAYOUT_NTHWC4 || planar) {
+    in4 = d_clips;  // already packed by tsm_preprocess (or read as it is by the stem): consumed in place
+    if (e->cur_timing) {  // keep the pack's launch slot: reported as "not recorded"
+      e->cur_timing->push_back(nullptr);
+      e->cur_timing->push_back(nullptr);
+    }
   } else {
     TSM_LAUNCH(e, s, tsm::launch_pack_input(d_clips, e->d_in4, n, cfg.height, cfg.width,
                                             layout == TSM_LAYOUT_NTCHW ? 1 : 0, prec, s));
@@ -429,9 +439,9 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
     // bf16 formats: dedicated direct-conv stem (LDS-resident input patch), with the max-pool fused behind it unless
     // the un-pooled tensor itself is wanted; TSM_STEM_DIRECT=0 / TSM_STEM_POOL=0 fall back (all forms bit-identical)
     const bool direct = prec != tsm::kPrecF32 && e->stem_direct;   // (fp32 has the pool-fused direct form only)
-    if (e->stem_direct && e->stem_pool && !want("conv1")) {
+    if (pool_stem) {
       TSM_LAUNCH(e, s, tsm::launch_stem_pool(in4, e->convs[0].d_w, e->convs[0].d_b, cur, n, cfg.height, cfg.width,
-                                              e->convs[0].kp, 1, prec, s));
+                                              e->convs[0].kp, 1, prec, s, planar ? 1 : 0));
       if (e->cur_timing) {  // keep the max-pool's launch slot: reported as "not recorded"
         e->cur_timing->push_back(nullptr);
         e->cur_timing->push_back(nullptr);
@@ -767,6 +777,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (const char *fd = getenv("TSM_FUSE_DOWNSAMPLE")) e->fuse_down = atoi(fd) != 0;
   if (const char *sd = getenv("TSM_STEM_DIRECT")) e->stem_direct = atoi(sd) != 0;
   if (const char *sp = getenv("TSM_STEM_POOL")) e->stem_pool = atoi(sp) != 0;
+  if (const char *pl = getenv("TSM_STEM_PLANAR")) e->stem_planar = atoi(pl) != 0;
   if (const char *ft = getenv("TSM_CONV_TILE")) e->force_tile = tsm::conv_tile_from_name(ft);
   if (const char *fc = getenv("TSM_CONV_CODE")) e->force_code = atoi(fc);
   if (const char *f23 = getenv("TSM_FUSE_CONV23")) e->fuse23 = atoi(f23) != 0;

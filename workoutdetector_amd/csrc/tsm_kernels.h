@@ -138,8 +138,10 @@ hipError_t launch_stem_direct(const float *x, const float *w, const float *bias,
                               int relu, int prec, hipStream_t s);
 // The same stem with the 3x3 stride-2 max-pool fused behind it: y is the POOLED tensor [n][hp][wp][64]; the stem's own
 // output is never materialised.  Bit-identical to launch_stem_direct followed by launch_maxpool3x3s2.
+// planar != 0: x is the [n][3][hi][wi] fp32 tensor (the reference model's input) and the kernel converts it the way
+// launch_pack_input would have -- the same bits without the pack launch and its packed copy.
 hipError_t launch_stem_pool(const float *x, const float *w, const float *bias, float *y, int n, int hi, int wi, int kp,
-                            int relu, int prec, hipStream_t s);
+                            int relu, int prec, hipStream_t s, int planar = 0);
 // Number of K segments of a launch with kseg_len > 0 (1 otherwise).
 int conv_num_segments(const ConvParams &p);
 // y = act(((p[0] + p[1]) + ...) + bias (+ res)) over fp32 partial tiles [n_seg][M*Cout] written by a ksplit launch.

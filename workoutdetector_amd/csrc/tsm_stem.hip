@@ -174,7 +174,11 @@ constexpr int kPoolPH = 7, kPoolPW = 8;                              // pooled t
 constexpr int kPoolCR = 2 * kPoolPH + 1, kPoolCC = 2 * kPoolPW + 1;  // conv tile 15 x 17
 constexpr int kPoolPR = 2 * kPoolCR + 5, kPoolPC = kPoolCC + 3;      // input patch 35 rows x 20 pixel pairs
 
-template <bool X3>
+// PLANAR: x is the caller's [N, 3, H, W] fp32 tensor itself (the reference model's input layout) instead of the packed pairs
+// pack_input_kernel would have written: a patch chunk is then six floats (two pixels x three colour planes) that are held
+// raw while the previous tile computes and rounded / split exactly as pack_input does (store_group's arithmetic) when the
+// patch is written to LDS -- same bits, and the forward loses the pack launch with its write and re-read of the packed tensor.
+template <bool X3, bool PLANAR>
 // (bf16: 77 760 B of LDS and <= 128 registers, so that TWO workgroups share a CU and overlap each other's phases)
 __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ bias, float *__restrict__ y, int n,
@@ -214,13 +218,18 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
 
   constexpr int PCH = kPoolPR * kPoolPC * GB / 16;
   constexpr int PPASS = (PCH + NT - 1) / NT;
-  u32x4 pre[PPASS];
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  u32x4 pre[PLANAR ? 1 : PPASS];
+  u32x2_t raw[PLANAR ? PPASS : 1][3];               // PLANAR: (pixel 2j, pixel 2j + 1) of each colour plane, fp32 bits
+  const unsigned plane_bytes = (unsigned)hi * wi * 4;
+  const bool even_w = (wi & 1) == 0;                // pairs never straddle a row end and are 8-byte aligned: one load per plane
   auto fetch_patch = [&](int t) {
     const int f = t / tiles_f, rem = t - f * tiles_f, ty = rem / tiles_x, tx = rem - ty * tiles_x;
     // conv tile origin (2*py0 - 1, 2*px0 - 1)  ->  input rows from 2*(2*py0 - 1) - 3, pairs from (2*px0 - 1) - 2
     const int iy0 = 4 * ty * kPoolPH - 5, pc0 = 2 * tx * kPoolPW - 3;
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(x) + (size_t)f * x_frame), 0, (int)x_frame, 0x00020000);
+        const_cast<char *>(reinterpret_cast<const char *>(x) + (size_t)f * (PLANAR ? 3 * (size_t)plane_bytes : (size_t)x_frame)), 0,
+        (int)(PLANAR ? 3 * plane_bytes : x_frame), 0x00020000);
 #pragma unroll
     for (int q = 0; q < PPASS; ++q) {
       const int ci = tid + q * NT;
@@ -228,8 +237,47 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
       const int r = g / kPoolPC, c = g - r * kPoolPC;
       const int iy = iy0 + r, pcx = pc0 + c;
       const bool ok = ci < PCH && (unsigned)iy < (unsigned)hi && (unsigned)pcx < (unsigned)wpairs;
-      const unsigned off = (unsigned)((iy * wpairs + pcx) * GB + (X3 ? (ci & 1) * 16 : 0));
-      pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)(ok ? off : kInvalid), 0, 0);
+      if constexpr (PLANAR) {
+        const unsigned off = (unsigned)((iy * wi + 2 * pcx) * 4);
+        const bool ok1 = ok && 2 * pcx + 1 < wi;
+        if (even_w) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            raw[q][pl] = __builtin_amdgcn_raw_buffer_load_b64(rsrcX, (int)(ok ? off : kInvalid), (int)(pl * plane_bytes), 0);
+        } else {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            raw[q][pl][0] = __builtin_amdgcn_raw_buffer_load_b32(rsrcX, (int)(ok ? off : kInvalid), (int)(pl * plane_bytes), 0);
+            raw[q][pl][1] = __builtin_amdgcn_raw_buffer_load_b32(rsrcX, (int)(ok1 ? off + 4u : kInvalid), (int)(pl * plane_bytes), 0);
+          }
+        }
+      } else {
+        const unsigned off = (unsigned)((iy * wpairs + pcx) * GB + (X3 ? (ci & 1) * 16 : 0));
+        pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)(ok ? off : kInvalid), 0, 0);
+      }
+    }
+  };
+  // PLANAR: the chunk pack_input_kernel would have stored for this thread's pair (store_group<bf16 / split-bf16>)
+  auto packed_chunk = [&](int q) -> u32x4 {
+    if constexpr (PLANAR) {
+      // (element -> scalar first: __builtin_bit_cast applied to a vector-ELEMENT expression reads element 0 whatever the
+      //  index with this hipcc -- the second pixel's loads were dropped and the first pixel's words stored twice)
+      const unsigned u0a = raw[q][0][0], u0b = raw[q][0][1], u1a = raw[q][1][0], u1b = raw[q][1][1], u2a = raw[q][2][0], u2b = raw[q][2][1];
+      const float c0a = __builtin_bit_cast(float, u0a), c0b = __builtin_bit_cast(float, u0b);
+      const float c1a = __builtin_bit_cast(float, u1a), c1b = __builtin_bit_cast(float, u1b);
+      const float c2a = __builtin_bit_cast(float, u2a), c2b = __builtin_bit_cast(float, u2b);
+      if constexpr (X3) {
+        unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+        split_pair(c0a, c1a, &h0, &l0);
+        split_pair(c2a, 0.f, &h1, &l1);
+        split_pair(c0b, c1b, &h2, &l2);
+        split_pair(c2b, 0.f, &h3, &l3);
+        return ((tid + q * NT) & 1) ? u32x4{l0, l1, l2, l3} : u32x4{h0, h1, h2, h3};
+      } else {
+        return u32x4{pack_bf16(c0a, c1a), pack_bf16(c2a, 0.f), pack_bf16(c0b, c1b), pack_bf16(c2b, 0.f)};
+      }
+    } else {
+      return pre[q];
     }
   };
   if ((int)blockIdx.x < n_tiles) fetch_patch((int)blockIdx.x);
@@ -242,7 +290,7 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < PPASS; ++q)
-      if (tid + q * NT < PCH) *reinterpret_cast<u32x4 *>(Ps + (tid + q * NT) * 16) = pre[q];
+      if (tid + q * NT < PCH) *reinterpret_cast<u32x4 *>(Ps + (tid + q * NT) * 16) = packed_chunk(q);
     if (t + gridDim.x < n_tiles) fetch_patch(t + gridDim.x);
     __syncthreads();
     f32x16 acc[2];
@@ -367,6 +415,7 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
 // the results are bit-identical to it (tap 49 is K padding: zero weights, its A operand re-reads tap 48).
 constexpr int kPoolPCF = 2 * (kPoolCC - 1) + 7;   // 39 input pixels per patch row
 
+template <bool PLANAR>   // (PLANAR: x = [N, 3, H, W] fp32, see stem_pool_kernel)
 __global__ void __launch_bounds__(512) stem_pool_f32_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                             const float *__restrict__ bias, float *__restrict__ y, int n,
                                                             int hi, int wi, int ho, int wo, int hp, int wp, int kp,
@@ -397,19 +446,28 @@ __global__ void __launch_bounds__(512) stem_pool_f32_kernel(const float *__restr
 
   constexpr int PCH = kPoolPR * kPoolPCF;
   constexpr int PPASS = (PCH + NT - 1) / NT;
-  u32x4 pre[PPASS];
+  u32x4 pre[PPASS];                                // (PLANAR: words 0-2 loaded from the three colour planes, word 3 = 0)
+  const unsigned plane_bytes = (unsigned)hi * wi * 4;
   auto fetch_patch = [&](long t) {
     const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
     const int iy0 = 4 * ty * kPoolPH - 5, ix0 = 4 * tx * kPoolPW - 5;   // 2 * (2 * p0 - 1) - 3
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(x) + (size_t)f * x_frame), 0, (int)x_frame, 0x00020000);
+        const_cast<char *>(reinterpret_cast<const char *>(x) + (size_t)f * (PLANAR ? 3 * (size_t)plane_bytes : (size_t)x_frame)), 0,
+        (int)(PLANAR ? 3 * plane_bytes : x_frame), 0x00020000);
 #pragma unroll
     for (int q = 0; q < PPASS; ++q) {
       const int ci = tid + q * NT;
       const int r = ci / kPoolPCF, c = ci - r * kPoolPCF;
       const int iy = iy0 + r, ix = ix0 + c;
       const bool ok = ci < PCH && (unsigned)iy < (unsigned)hi && (unsigned)ix < (unsigned)wi;
-      pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)(ok ? (unsigned)((iy * wi + ix) * 16) : kInvalid), 0, 0);
+      if constexpr (PLANAR) {
+        const unsigned off = ok ? (unsigned)((iy * wi + ix) * 4) : kInvalid;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) pre[q][pl] = __builtin_amdgcn_raw_buffer_load_b32(rsrcX, (int)off, (int)(pl * plane_bytes), 0);
+        pre[q][3] = 0u;
+      } else {
+        pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrcX, (int)(ok ? (unsigned)((iy * wi + ix) * 16) : kInvalid), 0, 0);
+      }
     }
   };
   if ((long)blockIdx.x < n_tiles) fetch_patch(blockIdx.x);
@@ -484,7 +542,7 @@ __global__ void __launch_bounds__(512) stem_pool_f32_kernel(const float *__restr
 }
 
 hipError_t launch_stem_pool(const float *x, const float *w, const float *bias, float *y, int n, int hi, int wi, int kp,
-                            int relu, int prec, hipStream_t s) {
+                            int relu, int prec, hipStream_t s, int planar) {
   const int ho = (hi + 6 - 7) / 2 + 1, wo = (wi + 6 - 7) / 2 + 1;
   const int hp = (ho + 2 - 3) / 2 + 1, wp = (wo + 2 - 3) / 2 + 1;
   if (!x || !w || !bias || !y || n <= 0 || hi <= 0 || wi <= 0 || kp < 200) return hipErrorInvalidValue;
@@ -494,12 +552,18 @@ hipError_t launch_stem_pool(const float *x, const float *w, const float *bias, f
   if (tiles >= (1L << 31) - 1024) return hipErrorInvalidValue;
   const long cap = (long)device_info().n_cu * (prec == kPrecBf16 ? 2 : 1);   // persistent: one 8-wave workgroup per CU (bf16: two)
   const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
-  if (prec == kPrecF32)
-    hipLaunchKernelGGL(stem_pool_f32_kernel, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
-  else if (prec == kPrecBf16)
-    hipLaunchKernelGGL(stem_pool_kernel<false>, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
-  else
-    hipLaunchKernelGGL(stem_pool_kernel<true>, dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu);
+#define TSM_STEM_ARGS dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu
+  if (prec == kPrecF32) {
+    if (planar) hipLaunchKernelGGL(stem_pool_f32_kernel<true>, TSM_STEM_ARGS);
+    else hipLaunchKernelGGL(stem_pool_f32_kernel<false>, TSM_STEM_ARGS);
+  } else if (prec == kPrecBf16) {
+    if (planar) hipLaunchKernelGGL((stem_pool_kernel<false, true>), TSM_STEM_ARGS);
+    else hipLaunchKernelGGL((stem_pool_kernel<false, false>), TSM_STEM_ARGS);
+  } else {
+    if (planar) hipLaunchKernelGGL((stem_pool_kernel<true, true>), TSM_STEM_ARGS);
+    else hipLaunchKernelGGL((stem_pool_kernel<true, false>), TSM_STEM_ARGS);
+  }
+#undef TSM_STEM_ARGS
   return hipGetLastError();
 }
 
