@@ -151,14 +151,21 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
     });
   };
 
+  // virtual frame index -> frame: XCD-chunked (the shifted quarter of conv1's input comes from frames f - 1 and f + 1: with
+  // a contiguous eighth of the frames per XCD its neighbours' workgroups fetch the same lines at about the same time), then
+  // the engine's alternating direction
+  auto frame_of = [&](int v) {
+    const int c = (int)xcd_chunked(v, p.N);
+    return p.reverse ? p.N - 1 - c : c;
+  };
   int fi = blockIdx.x;
-  if (fi < p.N) issue_x(p.reverse ? p.N - 1 - fi : fi, 0, true);
+  if (fi < p.N) issue_x(frame_of(fi), 0, true);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                         // biases and the zeroed line buffer are in place
 
   for (; fi < p.N; fi += gridDim.x) {
-    const int f = p.reverse ? p.N - 1 - fi : fi;
-    const int fnext = fi + (int)gridDim.x < p.N ? (p.reverse ? p.N - 1 - (fi + (int)gridDim.x) : fi + (int)gridDim.x) : -1;
+    const int f = frame_of(fi);
+    const int fnext = fi + (int)gridDim.x < p.N ? frame_of(fi + (int)gridDim.x) : -1;
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)f * xframe), 0, xframe, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(

@@ -34,6 +34,15 @@ constexpr int kBK = 32;
 
 constexpr unsigned kInvalid = 0x80000000u;  // >= num_records of every descriptor below
 
+// XCD-chunked tile order.  Workgroup b of a launch runs on XCD b & 7 (round-robin dispatch), and each XCD has an L2 of its
+// own: virtual index v = b + k * gridDim.x (gridDim.x a multiple of 8, or a single pass) is mapped to a tile such that every
+// XCD walks ONE contiguous eighth of the n tiles -- tiles that share halo lines, weights or neighbouring frames are then
+// fetched once per XCD instead of once per workgroup.  A bijection on [0, n) for any grid.
+__device__ __forceinline__ long xcd_chunked(long v, long n) {
+  const long q8 = n >> 3, r8 = n & 7, x = v & 7;
+  return (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (v >> 3);
+}
+
 // Cache policy of the activation stores of the bf16 kernel families (the aux operand of raw_buffer_store: 0 = plain,
 // 2 = nt, 16 = sc1 = write-through that drops the line from the XCD's L2, MI355X_MICROARCH.md "stores of each flavour").
 #ifndef TSM_OUT_AUX

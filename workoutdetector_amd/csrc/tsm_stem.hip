@@ -280,8 +280,10 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
       return pre[q];
     }
   };
-  if ((int)blockIdx.x < n_tiles) fetch_patch((int)blockIdx.x);
-  for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  // (tiles in XCD-chunked order: horizontally and vertically neighbouring tiles share up to half of their patch lines)
+  if ((int)blockIdx.x < n_tiles) fetch_patch((int)xcd_chunked(blockIdx.x, n_tiles));
+  for (int v = blockIdx.x; v < n_tiles; v += gridDim.x) {
+    const int t = (int)xcd_chunked(v, n_tiles);
     const int f = t / tiles_f, rem = t - f * tiles_f, ty = rem / tiles_x, tx = rem - ty * tiles_x;
     const int py0 = ty * kPoolPH, px0 = tx * kPoolPW;
     const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;   // conv pixel of tile position (0, 0)
@@ -291,7 +293,7 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
 #pragma unroll
     for (int q = 0; q < PPASS; ++q)
       if (tid + q * NT < PCH) *reinterpret_cast<u32x4 *>(Ps + (tid + q * NT) * 16) = packed_chunk(q);
-    if (t + gridDim.x < n_tiles) fetch_patch(t + gridDim.x);
+    if (v + (int)gridDim.x < n_tiles) fetch_patch((int)xcd_chunked(v + gridDim.x, n_tiles));
     __syncthreads();
     f32x16 acc[2];
 #pragma unroll
@@ -470,8 +472,9 @@ __global__ void __launch_bounds__(512) stem_pool_f32_kernel(const float *__restr
       }
     }
   };
-  if ((long)blockIdx.x < n_tiles) fetch_patch(blockIdx.x);
-  for (long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+  if ((long)blockIdx.x < n_tiles) fetch_patch(xcd_chunked(blockIdx.x, n_tiles));
+  for (long v = blockIdx.x; v < n_tiles; v += gridDim.x) {
+    const long t = xcd_chunked(v, n_tiles);   // (see stem_pool_kernel)
     const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y), f = (int)(t / ((long)tiles_x * tiles_y));
     const int py0 = ty * kPoolPH, px0 = tx * kPoolPW;
     const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;
@@ -481,7 +484,7 @@ __global__ void __launch_bounds__(512) stem_pool_f32_kernel(const float *__restr
 #pragma unroll
     for (int q = 0; q < PPASS; ++q)
       if (tid + q * NT < PCH) *reinterpret_cast<u32x4 *>(Ps + (tid + q * NT) * 16) = pre[q];
-    if (t + gridDim.x < n_tiles) fetch_patch(t + gridDim.x);
+    if (v + gridDim.x < n_tiles) fetch_patch(xcd_chunked(v + gridDim.x, n_tiles));
     __syncthreads();
     f32x16 acc[2];
 #pragma unroll

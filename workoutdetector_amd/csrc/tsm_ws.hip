@@ -670,16 +670,22 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
 #pragma unroll
     for (int e = 0; e < 16; ++e) accB[m][e] = 0.f;
   unsigned offA[2], offB[2] = {kInvalid, kInvalid};                     // nothing to store before the first tile
+  // virtual tile index -> tile: XCD-chunked (neighbouring tiles share halo rows and columns of their patches), then the
+  // engine's alternating direction
+  auto tile_of = [&](int v) {
+    const int c = (int)xcd_chunked(v, ntiles);
+    return p.reverse ? ntiles - 1 - c : c;
+  };
   int t = blockIdx.x, nb = 0;
-  if (t < ntiles) issue_patch(p.reverse ? ntiles - 1 - t : t, 0);
+  if (t < ntiles) issue_patch(tile_of(t), 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   if constexpr (S2) {
     // one pair per tile: the accumulator sets alternate from tile to tile (the epilogue of tile i rides on tile i + 1)
     auto step = [&](f32x16 (&cur)[2], const f32x16 (&prev)[2], const unsigned (&prev_off)[2], unsigned (&cur_off)[2]) {
       __builtin_amdgcn_s_barrier();    // every wave's share of this patch has landed; nobody still reads the other buffer
       const int tn = t + gridDim.x;
-      if (tn < ntiles) issue_patch(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
-      const int tt = p.reverse ? ntiles - 1 - t : t;
+      if (tn < ntiles) issue_patch(tile_of(tn), nb ^ 1);
+      const int tt = tile_of(t);
       mpair(lds + nb * kBuf, 0, cur, prev, prev_off);
       cur_off[0] = out_off(tt, 0); cur_off[1] = out_off(tt, 1);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                  // the next patch is older than this tile's four stores
@@ -704,8 +710,8 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
     for (; t < ntiles; t += gridDim.x, nb ^= 1) {
       __builtin_amdgcn_s_barrier();      // every wave's share of this patch has landed; nobody still reads the other buffer
       const int tn = t + gridDim.x;
-      if (tn < ntiles) issue_patch(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
-      const int tt = p.reverse ? ntiles - 1 - t : t;
+      if (tn < ntiles) issue_patch(tile_of(tn), nb ^ 1);
+      const int tt = tile_of(t);
       const unsigned char *buf = lds + nb * kBuf;
       mpair(buf, 0, accA, accB, offB);                                    // (B = M-tiles 2, 3 of the previous tile)
       offA[0] = out_off(tt, 0); offA[1] = out_off(tt, 1);
