@@ -106,7 +106,7 @@ def main(path, frames=256, size=224):
         tot += dur
         totf += fl
         kn = r['Kernel_Name'].split('<')[1].split('>')[0] if '<' in r['Kernel_Name'] else r['Kernel_Name'][:30]
-        if any(k in r['Kernel_Name'] for k in ('conv23_fused', 'conv_bf16_256', 'conv3x3_ws', 'conv1x1_ws', 'bneck_ws', 'conv31_fused')):
+        if any(k in r['Kernel_Name'] for k in ('conv23_fused', 'conv_bf16_256', 'conv3x3_ws', 'conv1x1_ws', 'bneck_ws', 'conv31_fused', 'stem_')):
             kn = r['Kernel_Name'].split('tsm::')[1].split('(')[0]
         grid = int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))
         print(f"{nm:34s} {kn:44s} wgs={grid:6d} {dur:8.1f}us {fl / dur / 1e6:7.1f} TF/s  vgpr={r.get('VGPR_Count','?')}")

@@ -28,15 +28,16 @@ def launches(dirname, counter):
     return [dict(Kernel_Name=names[d], value=per[d]) for d in ids if conv_like(names[d]) and 'splitk_reduce' not in names[d]]
 
 
-def algorithmic(parts, byname, frames, size, elt, label):
+def algorithmic(parts, byname, frames, size, elt, label, kernel=''):
     """(read, write) bytes of one launch that runs the layers ``parts``."""
+    planar = 'stem_pool' in kernel and kernel.rstrip().endswith('true>')     # the stem reads [N, 3, H, W] fp32 itself
     rd = wr = 0.0
     produced = set()
     for q in parts:
         r = byname[q]
         rd += r['cout'] * r['cin'] * r['k'] * r['k'] * (2 if elt == 2 else 4) / frames       # weights: once per launch
         if q == 'conv1':                                                                      # stem + max-pool: packed input (4 channels)
-            rd += size * size * 4 * elt
+            rd += size * size * (12 if planar else 4 * elt)
             hp = (size // 2 + 1) // 2
             wr += hp * hp * r['cout'] * elt
             continue
@@ -76,8 +77,8 @@ def main(fetch_dir, write_dir, frames, size, elt=2):
     tm = ta = 0.0
     for (nm, parts, a), (_, _, b) in zip(rf, rw):
         rd, wr = 2.0 * a['value'] * 1024, b['value'] * 1024
-        ard, awr = algorithmic(parts, byname, frames, size, elt, nm)
-        kn = a['Kernel_Name'].split('tsm::')[-1].split('(')[0][:46]
+        kn = a['Kernel_Name'].split('(')[0].split('tsm::')[-1][:46]
+        ard, awr = algorithmic(parts, byname, frames, size, elt, nm, kn)
         tm += rd + wr
         ta += ard + awr
         print(f'{nm:36s} {kn:46s} {rd / 1e6:9.1f} {wr / 1e6:9.1f} {ard / 1e6:9.1f} {awr / 1e6:10.1f} {(rd + wr) / (ard + awr):6.2f}')
