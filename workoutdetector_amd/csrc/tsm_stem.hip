@@ -365,6 +365,29 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
     if (tid < kPoolPH * kPoolPW * 8) {  // one 8-channel group of one pooled pixel per thread
       const int pp = tid >> 3, cg = tid & 7;
       const int pyl = pp / kPoolPW, pxl = pp - pyl * kPoolPW;
+      const int py = py0 + pyl, px = px0 + pxl;
+      const bool ok = py < hp && px < wp;
+      const unsigned base = ok ? (unsigned)((py * wp + px) * OPX + cg * GB) : kInvalid;
+      if constexpr (!X3) {
+        if (relu) {
+          // Behind a ReLU the tile holds bf16 bit patterns of non-negative numbers and 0xFF80 (-inf, outside the image): for
+          // those the 16-bit SIGNED integer order is the float order, so the 3x3 maximum is 4 v_pk_max_i16 per window
+          // position on the patterns themselves -- no unpacking, no re-packing (the float path below: ~150 instructions
+          // per 8 channels, on a kernel bound by its instruction count).  A NaN cannot be in the tile (fmaxf(NaN, 0) = 0
+          // in the conv epilogue); without the ReLU the values may be negative and the float path runs.
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          s16x8 mi = {(short)0xFF80, (short)0xFF80, (short)0xFF80, (short)0xFF80, (short)0xFF80, (short)0xFF80, (short)0xFF80, (short)0xFF80};
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const u32x4 pkd = *reinterpret_cast<const u32x4 *>(Cs16 + ((2 * pyl + ky) * kPoolCC + 2 * pxl + kx) * 72 + cg * 8);
+              mi = __builtin_elementwise_max(mi, __builtin_bit_cast(s16x8, pkd));
+            }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mi), rsrcY, (int)base, 0, 0);
+          continue;
+        }
+      }
       float m[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
@@ -387,9 +410,6 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
           m[0] = fmaxf(m[0], v0[0]); m[1] = fmaxf(m[1], v0[1]); m[2] = fmaxf(m[2], v0[2]); m[3] = fmaxf(m[3], v0[3]);
           m[4] = fmaxf(m[4], v1[0]); m[5] = fmaxf(m[5], v1[1]); m[6] = fmaxf(m[6], v1[2]); m[7] = fmaxf(m[7], v1[3]);
         }
-      const int py = py0 + pyl, px = px0 + pxl;
-      const bool ok = py < hp && px < wp;
-      const unsigned base = ok ? (unsigned)((py * wp + px) * OPX + cg * GB) : kInvalid;
       if constexpr (X3) {
         u32x4 oh, ol;
 #pragma unroll
