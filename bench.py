@@ -224,7 +224,7 @@ def self_launch(n, script=None):
     return worst
 
 
-def kernel_of(tile, dtype, cmid):
+def kernel_of(tile, dtype, cmid, stride=1):
     """rocprofv3's name (minus `void tsm::` and the parameter list) of the kernel a 3x3 launch with tile name `tile`
     (TsmEngine.tile_name) runs, and whether that launch also does the block's conv3 (+ residual)."""
     fused = tile.endswith('+conv3')
@@ -232,7 +232,7 @@ def kernel_of(tile, dtype, cmid):
     if main == 'ws':
         if cmid == 64:
             return 'conv3x3_ws_kernel<%s>' % ('true' if fused else 'false'), fused
-        return 'conv3x3_ws128_kernel', fused
+        return 'conv3x3_ws128_kernel<%s>' % ('true' if stride == 2 else 'false'), fused   # <S2>
     if fused:
         return 'conv23_fused_kernel<%d, %s>' % (cmid, 'true' if dtype == 'bf16x3' else 'false'), True
     if main == '256x256':
@@ -430,7 +430,7 @@ def main():
         # work it really does (its block's conv3 on top of the 3x3) and never mixed into the plain-3x3 group.
         groups = {}
         for r in dom:
-            kern, with_conv3 = kernel_of(tiles[r['name']], args.dtype, r['cout'])
+            kern, with_conv3 = kernel_of(tiles[r['name']], args.dtype, r['cout'], r['s'])
             gf = 2.0 * r['macs'] * frames / 1e9
             if with_conv3:
                 gf += 2.0 * table[r['name'].replace('.conv2', '.conv3')]['macs'] * frames / 1e9

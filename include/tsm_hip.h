@@ -70,7 +70,8 @@ typedef enum tsm_memkind { TSM_MEM_HOST = 0, TSM_MEM_DEVICE = 1 } tsm_memkind;
 
 /* Layout of the clip tensor handed to tsm_forward (T = num_segments). */
 typedef enum tsm_layout {
-  TSM_LAYOUT_NTCHW = 0, /* float32 [B,T,3,H,W]  -- the reference's ONNX input            */
+  TSM_LAYOUT_NTCHW = 0, /* float32 [B,T,3,H,W]  -- the reference's ONNX input; the stem kernel reads it as it is
+                           (rounds / splits while it stages its patch: no packed copy, no extra launch)           */
   TSM_LAYOUT_NTHWC = 1, /* float32 [B,T,H,W,3]  -- decoder-native, skips the host permute */
   TSM_LAYOUT_NTHWC4 = 2, /* float32 [B,T,H,W,4]  -- what tsm_preprocess writes for a TSM_DTYPE_F32 engine
                             (4th channel 0: the stem never reads it); device memory only, consumed in place without a repack */

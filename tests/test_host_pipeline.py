@@ -274,7 +274,7 @@ def test_bench_names_the_kernels_rocprof_prints():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     seen = {}
     for mode in ('f32', 'bf16c5', 'bf16x3'):
-        text = open(os.path.join(root, 'profiles', f'r03_{mode}_kernel_stats.csv')).read()
+        text = open(os.path.join(root, 'profiles', f'r04_{mode}_kernel_stats.csv')).read()
         seen[mode] = text
     cases = [('f32', '64x64', 'f32', 256), ('f32', '64x64+conv3', 'f32', 128), ('f32', '64x64+conv3', 'f32', 64),
              ('bf16c5', '256x256', 'bf16', 256), ('bf16c5', '256x256p', 'bf16', 256), ('bf16c5', 'ws', 'bf16', 128), ('bf16x3', '128x128w8', 'bf16x3', 256),
@@ -283,6 +283,8 @@ def test_bench_names_the_kernels_rocprof_prints():
         name, with_conv3 = bench.kernel_of(tile, dtype, cmid)
         assert with_conv3 == tile.endswith('+conv3')
         assert ('tsm::' + name) in seen[mode], (tile, dtype, cmid, name)
+    name, _ = bench.kernel_of('ws', 'bf16', 128, 2)           # layer2.0's conv2: the stride-2 arm
+    assert name == 'conv3x3_ws128_kernel<true>' and ('tsm::' + name) in seen['bf16c5']
     assert bench.kernel_of('ws+conv3', 'bf16', 64) == ('conv3x3_ws_kernel<true>', True)
     assert bench.kernel_of('64x64/splitK', 'f32', 512)[0] == 'conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, true>'
 
