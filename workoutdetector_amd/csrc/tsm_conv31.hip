@@ -98,6 +98,9 @@ template <int K3, int C, int N1, int CH> struct C31 {
   static_assert(kBytes <= 160 * 1024, "LDS budget");
 };
 
+#ifndef TSM_C31_X
+#define TSM_C31_X 0    // timing experiments only (wrong results): 1 no GEMM1, 2 no GEMM2, 4 no residual loads, 8 no y stores, 16 no weight DMA, 32 no chunk epilogue ALU/LDS
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt_imm() {
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -200,12 +203,12 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
   };
   auto issue_w3 = [&](int nc, unsigned dead) {
 #pragma unroll
-    for (int i = 0; i < L::NW3; ++i)
+    for (int i = 0; i < ((TSM_C31_X & 16) ? 0 : L::NW3); ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW3, (lds_void *)(lds + L::kW3 + (wave * L::NW3 + i) * 1024), 16,
                                                (int)(w3off[i] | dead), nc * 64 * rb3, 0, 0);
   };
   auto issue_w1_piece = [&](int nc, int i) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW1, (lds_void *)(lds + L::kW1 + (wave * L::NW1 + i) * 1024), 16,
+    if (!(TSM_C31_X & 16)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW1, (lds_void *)(lds + L::kW1 + (wave * L::NW1 + i) * 1024), 16,
                                              (int)w1off[i], nc * 128, 0, 0);
   };
   // STAGE: pieces i0 .. i0 + n - 1 of the t2 tile (clip, p0) into the staging buffer
@@ -236,7 +239,8 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.res) + (size_t)clip * clip_rows * (C * 2)), 0, (int)(clip_rows * (C * 2)), 0x00020000);
     const unsigned inv = (unsigned)p0 + epx[q] < (unsigned)HW ? 0u : kInvalid;
-    rres[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(evoff[q] | inv | dead), p0 * cb + nc * 128, 0);
+    if (!(TSM_C31_X & 4)) rres[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(evoff[q] | inv | dead), p0 * cb + nc * 128, 0);
+    else rres[slot] = u32x4{(unsigned)slot, 0u, 0u, 0u};
   };
 
   // ---- prologue: the first tile's t2, the first chunk of W3, the first chunk's residual ----------------------------
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
           ring[m] = *reinterpret_cast<const u32x4 *>(lds + (ba ^ (unsigned)((m / L::NTL1) << 5)) + (m % L::NTL1) * 32 * L::RB3);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
+        for (int m = 0; m < ((TSM_C31_X & 1) ? 0 : NM); ++m) {
           const u32x4 b = ring[m % D];
           if (m + D < NM)
             ring[m % D] = *reinterpret_cast<const u32x4 *>(lds + (ba ^ (unsigned)(((m + D) / L::NTL1) << 5)) + ((m + D) % L::NTL1) * 32 * L::RB3);
@@ -340,7 +344,7 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
       const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(bias3_l + nc * 64 + c8 * 8);
       const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(bias3_l + nc * 64 + c8 * 8 + 4);
 #pragma unroll
-      for (int q = 0; q < L::NQ; ++q) {
+      for (int q = 0; q < ((TSM_C31_X & 32) ? 0 : L::NQ); ++q) {
         f32x4 c0, c1;
         if constexpr (L::STAGE) {
 #pragma unroll
@@ -373,7 +377,7 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
         u32x4 o;
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2) o[w2] = pack_bf16(fmaxf(v[2 * w2], 0.f), fmaxf(v[2 * w2 + 1], 0.f));
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(evoff[q] | einv[q]), p0 * cb + nc * 128, TSM_AUX_C31);
+        if (!(TSM_C31_X & 8)) __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)(evoff[q] | einv[q]), p0 * cb + nc * 128, TSM_AUX_C31);
         *reinterpret_cast<u32x4 *>(lds + yw[q]) = o;
         if (nc + L::RD < L::NC) load_res(rset * L::NQ + q, q, clip, p0, nc + L::RD, 0u);
         else load_res(rset * L::NQ + q, q, nclip, np0, nc + L::RD - L::NC, next_dead);
@@ -406,7 +410,7 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
           ring[m] = *reinterpret_cast<const u32x4 *>(lds + (bb ^ (unsigned)((m / L::NTL2) << 5)) + (m % L::NTL2) * 32 * 128);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < NM; ++m) {
+        for (int m = 0; m < ((TSM_C31_X & 2) ? 0 : NM); ++m) {
           const u32x4 b = ring[m % D];
           if (m + D < NM)
             ring[m % D] = *reinterpret_cast<const u32x4 *>(lds + (bb ^ (unsigned)(((m + D) / L::NTL2) << 5)) + ((m + D) % L::NTL2) * 32 * 128);
