@@ -173,6 +173,22 @@ def test_stem_reading_the_reference_layout_equals_the_packed_input_bitwise(hip_l
     assert np.isfinite(got['1'][1]).all() and np.abs(got['1'][0]).max() > 0
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+def test_a_reference_layout_tensor_that_is_only_4_byte_aligned_gives_the_same_logits(hip_lib, sd0, dtype):
+    """The fp32-reading stem loads pixel pairs with 8-byte loads: a device pointer that is not 16-byte aligned (a view one
+    float into a larger buffer) takes the pack launch instead -- same bits either way."""
+    from workoutdetector_amd.engine import TsmEngine
+    x = torch.from_numpy(make_input(77, 2, 8, 64, 64)).cuda()
+    buf = torch.empty(x.numel() + 1, dtype=torch.float32, device='cuda')
+    xm = buf[1:].view_as(x)
+    xm.copy_(x)
+    assert xm.data_ptr() % 16 == 4 and xm.is_contiguous()
+    eng = TsmEngine(height=64, width=64, max_clips=2, state_dict=sd0, dtype=dtype)
+    a, b = eng.forward_device(x).cpu(), eng.forward_device(xm).cpu()
+    eng.close()
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+
+
 @pytest.mark.parametrize('n,hi,wi,cin,cout,k,stride,relu,shiftT,use_res', [
     (8, 16, 16, 256, 256, 3, 1, True, 0, False),   # layer3 conv2 at the config-5 size: 2048 rows = 8 full tiles
     (4, 16, 16, 256, 256, 3, 2, True, 0, False),   # stride 2 (layer3.0 / layer4.0 conv2): 256 rows

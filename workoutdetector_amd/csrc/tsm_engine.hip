@@ -418,8 +418,9 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   // The pool-fused stem reads the reference layout ([N, T, 3, H, W] fp32) itself and converts while it stages its patch:
   // no pack launch, no packed copy (TSM_STEM_PLANAR=0 and every other stem form keep the pack; all bit-identical).
   const bool pool_stem = e->stem_direct && e->stem_pool && !want("conv1");
+  // (8-byte loads of pixel pairs: a caller's pointer that is only 4-byte aligned takes the pack launch, which loads floats)
   const bool planar = layout == TSM_LAYOUT_NTCHW && e->stem_planar && pool_stem && !want("input") &&
-                      (double)cfg.height * cfg.width * 12.0 < 2.0e9;
+                      (double)cfg.height * cfg.width * 12.0 < 2.0e9 && (reinterpret_cast<uintptr_t>(d_clips) & 15u) == 0;
   if (layout >= TSM_LAYOUT_NTHWC4 || planar) {
     in4 = d_clips;  // already packed by tsm_preprocess (or read as it is by the stem): consumed in place
     if (e->cur_timing) {  // keep the pack's launch slot: reported as "not recorded"
