@@ -114,8 +114,8 @@ def test_whole_bottleneck_kernel_budget(md):
     its step loop would also break its counted vmcnt waits: scratch accesses count as vector-memory operations), and
     150 016 B of dynamic LDS = one workgroup per CU."""
     for cin, lds in ((256, 150016), (64, 133632)):
-        for shift in ('true', 'false'):
-            r = _one(md, f'bneck_ws_kernel<{cin}, {shift}>')
+        for shift, idl in (('true', 'false'), ('false', 'false')) + ((('true', 'true'), ('false', 'true')) if cin == 256 else ()):
+            r = _one(md, f'bneck_ws_kernel<{cin}, {shift}, {idl}>')     # (<.., true>: row 2s of the identity from the LDS input slots)
             assert r['.max_flat_workgroup_size'] == 256 and r['.vgpr_count'] <= 512 and r['.agpr_count'] >= 160
             assert r['.vgpr_count'] - r['.agpr_count'] <= 256        # architectural VGPRs incl. the MFMA results (vgpr-form build)
             assert r['.private_segment_fixed_size'] == 0 and r['.vgpr_spill_count'] == 0

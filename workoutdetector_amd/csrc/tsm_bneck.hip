@@ -62,9 +62,18 @@ template <int CIN> struct BnLds {
 
 // SHIFT: the temporal shift of conv1's input, fold = CIN / 8 channels from frame t + 1 and as many from t - 1 (the bf16
 // formats take shift_div 8 only) -- compile-time, so that a chunk's source row is a register choice and not a table lookup.
-template <int CIN, bool SHIFT>
+// IDL (CIN = 256, W = 64): half of conv3's identity operand is taken from the input slots in LDS instead of a second read
+// of the block input.  With full-width rows of 64 pixels a step's 128 input pixels are exactly the four waves' slots, and
+// output row 2s (M-tiles 2, 3) is the FIRST row of this step's input = slots 0, 1: once every slot has landed (one more
+// barrier at the top of a step) each wave copies its 64 output channels of those two slots into the registers the late
+// identity loads used to fill, and the slots are re-armed behind the conv1 barrier instead of inside the phase.  Output row
+// 2s - 1 (M-tiles 0, 1) was the second row of the PREVIOUS step's input: holding it for a step takes 32 registers the file
+// does not have (built: 512 registers and 20 spills), so it still comes from memory.  With the temporal shift the first 64
+// channels of a slot come from frames t +- 1, so the wave that owns output channels 0-63 keeps loading all of its identity.
+template <int CIN, bool SHIFT, bool IDL = false>
 __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
   constexpr bool DUAL = CIN == 64;
+  static_assert(!IDL || CIN == 256, "the LDS identity is the 256-channel form's");
   constexpr int NG1 = CIN / 16;                    // k16 groups of conv1 = planes of an input slot
   constexpr int NG3 = BnLds<CIN>::kNG3;
   constexpr int XROW = CIN * 2;                    // bytes per input pixel
@@ -125,6 +134,12 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
   const int dr1 = m1 >= W ? 1 : 0, c1 = m1 - dr1 * W;
   const bool ok1 = m1 < W2;
 
+  // IDL: does THIS wave take its identity from LDS (wave-uniform), and where: 16-byte group 2 half + qq of the 64-byte slice
+  // it = 2 wave + itl of pixel l31 of a slot = plane 2 it + half, half qq of the pixel's entry
+  const bool idl = IDL && (!SHIFT || wave != 0);
+  const unsigned idrd = (unsigned)(kBnXOff + (2 * (2 * wave) + half) * 1024 + l31 * 32);
+  const unsigned idflip = (unsigned)((l31 >> 3) & 1);
+
   // LDS-DMA of the input of step s of frame f into this wave's slot: always NDMA operations (dead ones fetch nothing)
   auto issue_x = [&](int f, int s, bool live) {
     const int tt = p.T > 0 ? f % p.T : 0;
@@ -179,13 +194,23 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
       const int r0 = 2 * s - 1;                                         // output rows r0, r0 + 1; conv1 rows 2s, 2s + 1
       // ================= conv1: rows 2s, 2s + 1 -> line buffer =================
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                 // this step's input has landed (the 16 youngest operations are the previous step's stores)
+      if constexpr (IDL) __builtin_amdgcn_s_barrier();                  // ... every wave's: the identity below is read from all four slots
       // The identity operand of this step's four M-tiles, 4 x 16 bytes per lane and M-tile:
       //   CIN 256  res[mt][2 itl + qq] = bytes [64 it + 16 (2 half + qq), + 16) of the pixel's 512 (the store layout);
       //   CIN 64   res[mt][g] = channels 16 g + 8 half .. + 8 of the pixel: the B fragment of k16 group g.
       // Issue order of a step's vector-memory operations: [8 identity loads, M-tiles 0-1 (conv1 phase) | NDMA LDS-DMA of
       // the next step's input | 8 identity loads, M-tiles 2-3 (top of the conv2 phase) | 16 stores] -- every wait below counts on it.
       u32x4 res[4][4];
+      // IDL: this step's M-tiles 2, 3 (row 2s) from slots 0, 1
+      auto capture_res = [&]() {
+#pragma unroll
+        for (int ws = 0; ws < 2; ++ws)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            res[2 + ws][k] = *reinterpret_cast<const u32x4 *>(lds + idrd + ws * kSlot + (k >> 1) * 2048 + ((((unsigned)(k & 1)) ^ idflip) << 4));
+      };
       auto issue_res = [&](int mt) {
+        if (idl && mt >= 2) return;
         const int m = 32 * mt + l31;
         const int dr = m >= W ? 1 : 0, c = m - dr * W, r = r0 + dr;
         const bool ok = m < W2 && (unsigned)r < (unsigned)H;
@@ -216,9 +241,11 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
           if (gh == NG1 / GH - 1) {
             issue_res(0);
             issue_res(1);
-            // the slot is free (its fragments are in registers): fetch the next step's input, a whole step ahead
-            if (s + 1 < nsteps) issue_x(f, s + 1, true);
-            else issue_x(fnext < 0 ? f : fnext, 0, fnext >= 0);
+            if constexpr (!IDL) {
+              // the slot is free (its fragments are in registers): fetch the next step's input, a whole step ahead
+              if (s + 1 < nsteps) issue_x(f, s + 1, true);
+              else issue_x(fnext < 0 ? f : fnext, 0, fnext >= 0);
+            }
           }
 #pragma unroll
           for (int g = 0; g < GH; ++g)
@@ -226,6 +253,9 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
             for (int nt = 0; nt < 2; ++nt)
               acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1r[nt][GH * gh + g]), __builtin_bit_cast(bf16x8, xf[g]), acc[nt], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (IDL) {             // (behind the MFMAs: the slot's fragment registers are free, the reads land under the epilogue)
+          if (idl) capture_res();
         }
         // bias1, ReLU, bf16; the swap pairs groups (0, 1) and (2, 3): this lane then holds channels 16 g' + 8 half .. + 8 of
         // k16 group g' = 2 nt + qq of its pixel = one 16-byte half of the pixel's entry in plane g' of the line buffer
@@ -253,6 +283,10 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();    // rows 2s - 2 .. 2s + 1 are complete; nobody still reads the mid tile of the previous step
+      if constexpr (IDL) {             // ... nor anybody's input slot: re-arm it (a step minus the conv1 phase ahead)
+        if (s + 1 < nsteps) issue_x(f, s + 1, true);
+        else issue_x(fnext < 0 ? f : fnext, 0, fnext >= 0);
+      }
       // ================= conv2: output rows r0, r0 + 1, M-tiles 2 hh, 2 hh + 1, mid channels 32 nt2 .. + 32 =================
       issue_res(2);
       issue_res(3);
@@ -344,8 +378,9 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
         // this M-tile's identity operand; younger operations: M-tiles 0, 1 -- the other early loads (4 / 0), the next input
         // (NDMA), the late loads (8), the stores so far (0 / 4) = NDMA + 12; M-tiles 2, 3 -- the other late loads and the
         // stores so far = 12
-        if constexpr (mt < 2) wait_vmcnt(NDMA + 12);
-        else wait_vmcnt(12);
+        // (IDL waves issue no late loads: [8 early loads | NDMA | 16 stores], and M-tiles 2, 3 wait for nothing)
+        if constexpr (mt < 2) wait_vmcnt(idl ? NDMA + 4 : NDMA + 12);
+        else if (!idl) wait_vmcnt(12);
         if constexpr (DUAL) {   // the downsample branch: K continues over the block input's 64 channels
 #pragma unroll
           for (int g = 0; g < 4; ++g)
@@ -416,7 +451,10 @@ hipError_t launch_bneck_ws(const BneckParams &p, hipStream_t s) {
   const DeviceInfo &di = device_info();
   if (di.status != hipSuccess) return di.status;
   const dim3 grid((unsigned)(p.N < di.n_cu ? p.N : di.n_cu)), block(256);
-  if (p.cin == 256) {
+  if (p.cin == 256 && p.W == 64) {   // the identity from the input slots in LDS
+    if (p.T > 0) hipLaunchKernelGGL((bneck_ws_kernel<256, true, true>), grid, block, BnLds<256>::kBytes, s, p);
+    else hipLaunchKernelGGL((bneck_ws_kernel<256, false, true>), grid, block, BnLds<256>::kBytes, s, p);
+  } else if (p.cin == 256) {
     if (p.T > 0) hipLaunchKernelGGL((bneck_ws_kernel<256, true>), grid, block, BnLds<256>::kBytes, s, p);
     else hipLaunchKernelGGL((bneck_ws_kernel<256, false>), grid, block, BnLds<256>::kBytes, s, p);
   } else {
@@ -434,6 +472,8 @@ hipError_t opt_in_bneck() {
   };
   opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, true>), BnLds<256>::kBytes);
   opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, false>), BnLds<256>::kBytes);
+  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, true, true>), BnLds<256>::kBytes);
+  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, false, true>), BnLds<256>::kBytes);
   opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<64, true>), BnLds<64>::kBytes);
   opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<64, false>), BnLds<64>::kBytes);
   return first;
