@@ -429,6 +429,10 @@ def test_weight_stationary_kernels_on_random_shapes_bitwise(hip_lib, monkeypatch
     (270, 480, 1, 8, 8, True),     # 68 x 120: too wide for the line buffer -- the forced switch must fall back, same bits
     (32, 32, 5, 1, 8, True),       # the smallest engine: 8 x 8 frames, single-frame clips (both shifted groups read zeros)
     (250, 256, 1, 4, 8, True),     # 63 x 64: the widest row with an odd height; 4 frames on 4 workgroups
+    (256, 256, 1, 8, 8, False),    # 64-wide rows without the shift: all four waves take their identity from the LDS input slots
+    (256, 256, 5, 1, 8, True),     # ... single-frame clips (the shifted channels are zeros, the wave that owns them still loads its identity)
+    (130, 256, 3, 4, 8, True),     # ... 33 x 64 frames: odd height, 12 frames
+    (32, 256, 2, 8, 8, True),      # ... 8 x 64 frames: five steps per frame, the row held across a step changes frame every fifth
 ])
 def test_whole_bottleneck_kernel_equals_the_separate_launches_bitwise(hip_lib, monkeypatch, h, w, b, t, div, shift):
     """bneck_ws_kernel (every layer1 block in bf16 as ONE launch: shift + conv1 into an LDS line buffer, conv2 from it,

@@ -58,6 +58,8 @@ template <int CIN> struct BnLds {
   static constexpr int kNG3 = CIN == 64 ? 8 : 4;                // k16 groups of conv3's K (the downsample form: mid + input)
   static constexpr int kBiasOff = kW3Off + 8 * kNG3 * 1024;
   static constexpr int kBytes = kBiasOff + (64 + 64 + 256) * 4; // 150 016 B (CIN 256) / 133 632 B (CIN 64)
+  static constexpr int kW1pOff = kBytes;                        // IDL: k16 groups 8-15 of W1's second tile, fragment order (8 KB)
+  static constexpr int kBytesIdl = kW1pOff + 8 * 1024;          // 158 208 B
 };
 
 // SHIFT: the temporal shift of conv1's input, fold = CIN / 8 channels from frame t + 1 and as many from t - 1 (the bf16
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int nt2 = wave & 1, hh = wave >> 1;
-  const int H = p.H, W = p.W, W2 = 2 * W;
+  const int H = p.H, W = IDL ? 64 : p.W, W2 = 2 * W;   // (IDL is launched for W = 64 only: a constant there)
   const int xframe = H * W * XROW, yframe = H * W * 512;
   const int nsteps = H / 2 + 1;
 
@@ -97,11 +99,21 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
 #pragma unroll
   for (int s = 0; s < 36; ++s)
     w2r[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW2, ((nt2 * 32 + l31) * 576 + s * 16 + half * 8) * 2, 0, 0);
+  // IDL: the second tile's k16 groups 8-15 live in LDS (one copy for the four waves, read once per step): 32 registers
+  // for the identity set that is held across a step
+  constexpr int kW1pOff = BnLds<CIN>::kW1pOff;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int g = 0; g < NG1; ++g)
-      w1r[nt][g] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW1, ((nt * 32 + l31) * CIN + g * 16 + half * 8) * 2, 0, 0);
+    for (int g = 0; g < NG1; ++g) {
+      if (IDL && nt == 1 && g >= 8) {
+        if (wave == ((g - 8) >> 1))
+          *reinterpret_cast<u32x4 *>(lds + kW1pOff + (g - 8) * 1024 + lane * 16) =
+              __builtin_amdgcn_raw_buffer_load_b128(rsrcW1, ((nt * 32 + l31) * CIN + g * 16 + half * 8) * 2, 0, 0);
+      } else {
+        w1r[nt][g] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW1, ((nt * 32 + l31) * CIN + g * 16 + half * 8) * 2, 0, 0);
+      }
+    }
   // W3 (2 x NG3 fragments per wave) stays in LDS: a step reads it once, into registers that are free in the conv3 phase
 #pragma unroll
   for (int k = 0; k < 2 * NG3; ++k) {
@@ -140,6 +152,12 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
   const unsigned idrd = (unsigned)(kBnXOff + (2 * (2 * wave) + half) * 1024 + l31 * 32);
   const unsigned idflip = (unsigned)((l31 >> 3) & 1);
 
+  u32x4 nxt[IDL ? 2 : 1][4];
+#pragma unroll
+  for (int mt = 0; mt < (IDL ? 2 : 1); ++mt)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nxt[mt][k] = u32x4{0u, 0u, 0u, 0u};
+
   // LDS-DMA of the input of step s of frame f into this wave's slot: always NDMA operations (dead ones fetch nothing)
   auto issue_x = [&](int f, int s, bool live) {
     const int tt = p.T > 0 ? f % p.T : 0;
@@ -170,7 +188,8 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
   // a contiguous eighth of the frames per XCD its neighbours' workgroups fetch the same lines at about the same time), then
   // the engine's alternating direction
   auto frame_of = [&](int v) {
-    const int c = (int)xcd_chunked(v, p.N);
+    const int n = p.N, q8 = n >> 3, r8 = n & 7, x = v & 7;          // xcd_chunked() in 32 bits (scalar registers are short here)
+    const int c = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (v >> 3);
     return p.reverse ? p.N - 1 - c : c;
   };
   int fi = blockIdx.x;
@@ -201,16 +220,24 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
       // Issue order of a step's vector-memory operations: [8 identity loads, M-tiles 0-1 (conv1 phase) | NDMA LDS-DMA of
       // the next step's input | 8 identity loads, M-tiles 2-3 (top of the conv2 phase) | 16 stores] -- every wait below counts on it.
       u32x4 res[4][4];
-      // IDL: this step's M-tiles 2, 3 (row 2s) from slots 0, 1
+      // IDL: this step's M-tiles 2, 3 (row 2s) from slots 0, 1; the NEXT step's M-tiles 0, 1 (row 2s + 1) from slots 2, 3,
+      // parked in accumulation registers for a step
       auto capture_res = [&]() {
 #pragma unroll
-        for (int ws = 0; ws < 2; ++ws)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            res[2 + ws][k] = *reinterpret_cast<const u32x4 *>(lds + idrd + ws * kSlot + (k >> 1) * 2048 + ((((unsigned)(k & 1)) ^ idflip) << 4));
+          for (int k = 0; k < 4; ++k) res[mt][k] = nxt[mt][k];
+#pragma unroll
+        for (int ws = 0; ws < 4; ++ws)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + idrd + ws * kSlot + (k >> 1) * 2048 + ((((unsigned)(k & 1)) ^ idflip) << 4));
+            if (ws < 2) res[2 + ws][k] = v;
+            else nxt[ws - 2][k] = v;
+          }
       };
       auto issue_res = [&](int mt) {
-        if (idl && mt >= 2) return;
+        if (idl) return;
         const int m = 32 * mt + l31;
         const int dr = m >= W ? 1 : 0, c = m - dr * W, r = r0 + dr;
         const bool ok = m < W2 && (unsigned)r < (unsigned)H;
@@ -247,11 +274,24 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
               else issue_x(fnext < 0 ? f : fnext, 0, fnext >= 0);
             }
           }
+          // (IDL: the parked fragments of the second tile, four at a time)
 #pragma unroll
-          for (int g = 0; g < GH; ++g)
+          for (int g4 = 0; g4 < GH; g4 += 4) {
+            u32x4 w1p[4];
+            if constexpr (IDL) {
+              if (gh == 1) {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1r[nt][GH * gh + g]), __builtin_bit_cast(bf16x8, xf[g]), acc[nt], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) w1p[g] = *reinterpret_cast<const u32x4 *>(lds + kW1pOff + (g4 + g) * 1024 + lane * 16);
+              }
+            }
+#pragma unroll
+            for (int g = g4; g < g4 + 4; ++g)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) {
+                const u32x4 wf = (IDL && nt == 1 && gh == 1) ? w1p[g - g4] : w1r[nt][GH * gh + g];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf[g]), acc[nt], 0, 0, 0);
+              }
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (IDL) {             // (behind the MFMAs: the slot's fragment registers are free, the reads land under the epilogue)
@@ -379,8 +419,10 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
         // (NDMA), the late loads (8), the stores so far (0 / 4) = NDMA + 12; M-tiles 2, 3 -- the other late loads and the
         // stores so far = 12
         // (IDL waves issue no late loads: [8 early loads | NDMA | 16 stores], and M-tiles 2, 3 wait for nothing)
-        if constexpr (mt < 2) wait_vmcnt(idl ? NDMA + 4 : NDMA + 12);
-        else if (!idl) wait_vmcnt(12);
+        if (!idl) {
+          if constexpr (mt < 2) wait_vmcnt(NDMA + 12);
+          else wait_vmcnt(12);
+        }
         if constexpr (DUAL) {   // the downsample branch: K continues over the block input's 64 channels
 #pragma unroll
           for (int g = 0; g < 4; ++g)
@@ -452,8 +494,8 @@ hipError_t launch_bneck_ws(const BneckParams &p, hipStream_t s) {
   if (di.status != hipSuccess) return di.status;
   const dim3 grid((unsigned)(p.N < di.n_cu ? p.N : di.n_cu)), block(256);
   if (p.cin == 256 && p.W == 64) {   // the identity from the input slots in LDS
-    if (p.T > 0) hipLaunchKernelGGL((bneck_ws_kernel<256, true, true>), grid, block, BnLds<256>::kBytes, s, p);
-    else hipLaunchKernelGGL((bneck_ws_kernel<256, false, true>), grid, block, BnLds<256>::kBytes, s, p);
+    if (p.T > 0) hipLaunchKernelGGL((bneck_ws_kernel<256, true, true>), grid, block, BnLds<256>::kBytesIdl, s, p);
+    else hipLaunchKernelGGL((bneck_ws_kernel<256, false, true>), grid, block, BnLds<256>::kBytesIdl, s, p);
   } else if (p.cin == 256) {
     if (p.T > 0) hipLaunchKernelGGL((bneck_ws_kernel<256, true>), grid, block, BnLds<256>::kBytes, s, p);
     else hipLaunchKernelGGL((bneck_ws_kernel<256, false>), grid, block, BnLds<256>::kBytes, s, p);
@@ -472,8 +514,8 @@ hipError_t opt_in_bneck() {
   };
   opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, true>), BnLds<256>::kBytes);
   opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, false>), BnLds<256>::kBytes);
-  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, true, true>), BnLds<256>::kBytes);
-  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, false, true>), BnLds<256>::kBytes);
+  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, true, true>), BnLds<256>::kBytesIdl);
+  opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<256, false, true>), BnLds<256>::kBytesIdl);
   opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<64, true>), BnLds<64>::kBytes);
   opt_in(reinterpret_cast<const void *>(&bneck_ws_kernel<64, false>), BnLds<64>::kBytes);
   return first;
