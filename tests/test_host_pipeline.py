@@ -1,6 +1,7 @@
 """Host side of the hot path on CPU with a stub model: clip windows, transform, JSON schema, evaluation."""
 import json
 import os
+import sys
 
 import numpy as np
 import pandas as pd
@@ -287,6 +288,40 @@ def test_bench_names_the_kernels_rocprof_prints():
     assert name == 'conv3x3_ws128_kernel<true>' and ('tsm::' + name) in seen['bf16c5']
     assert bench.kernel_of('ws+conv3', 'bf16', 64) == ('conv3x3_ws_kernel<true>', True)
     assert bench.kernel_of('64x64/splitK', 'f32', 512)[0] == 'conv_igemm<64, 64, 2, 2, 3, false, false, 0, false, true>'
+
+
+def test_profiling_tools_find_the_forwards_with_and_without_a_pack_launch():
+    """tools/hbm_traffic.forward_starts delimits the forwards of a kernel trace: by the pack launch of an NTCHW input, or --
+    since the pool-fused stem reads that layout itself -- by a stem launch that no pack precedes; tools/layer_times matches
+    a forward's launches to layers whether or not conv3 of a block also ran the next block's conv1."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    try:
+        from hbm_traffic import forward_starts
+        from layer_times import match_schedule
+    finally:
+        sys.path.pop(0)
+    fwd_pack = ['tsm::pack_input_kernel<2>', 'tsm::stem_pool_kernel<false, false>', 'tsm::bneck_ws_kernel<64, true, false>', 'tsm::head_fc_kernel']
+    fwd_planar = ['tsm::stem_pool_kernel<false, true>', 'tsm::bneck_ws_kernel<64, true, false>', 'tsm::head_fc_kernel']
+    assert forward_starts(fwd_pack * 3) == [0, 4, 8]
+    assert forward_starts(fwd_planar * 3) == [0, 3, 6]
+    assert forward_starts(fwd_pack + fwd_planar + fwd_pack) == [0, 4, 7]
+    # one bf16 forward as the engine launches it at config 5: whole-block layer1, cross-block launches in layer2-3
+    names = ['stem_pool_kernel<false, true>'] + ['bneck_ws_kernel<64, true, false>'] + ['bneck_ws_kernel<256, true, true>'] * 2
+    names += ['conv1x1_wsn_kernel<256, 128, false>', 'conv3x3_ws128_kernel<true>', 'conv_bf16_256p_kernel<1, false, false, true>']      # layer2.0
+    names += ['conv1x1_wsn_kernel<512, 128, false>', 'conv3x3_ws128_kernel<false>', 'conv31_fused_kernel<128, 512, 128, 1>']           # layer2.1 (+ 2.2.conv1)
+    names += ['conv3x3_ws128_kernel<false>', 'conv31_fused_kernel<128, 512, 128, 1>', 'conv3x3_ws128_kernel<false>', 'conv31_fused_kernel<128, 512, 256, 2>']
+    names += ['conv_bf16_256p_kernel<3, false, false, false>', 'conv_bf16_256p_kernel<1, false, false, true>']                          # layer3.0 (conv1 came fused)
+    names += ['conv_bf16_256p_kernel<1, true, false, false>'] + ['conv_bf16_256p_kernel<3, false, false, false>', 'conv31_fused_kernel<256, 1024, 256, 2>'] * 4
+    names += ['conv_bf16_256p_kernel<3, false, false, false>', 'conv_bf16_256p_kernel<1, false, true, false>']                           # layer3.5
+    names += ['conv_bf16_256p_kernel<1, true, false, false>', 'conv_bf16_256p_kernel<3, false, false, false>', 'conv_bf16_256p_kernel<1, false, false, true>']
+    names += ['conv_bf16_256p_kernel<1, true, false, false>', 'conv_bf16_256p_kernel<3, false, false, false>', 'conv_bf16_256p_kernel<1, false, true, false>'] * 2
+    rows, ok = match_schedule([dict(Kernel_Name='void tsm::' + n + '(tsm::ConvParams)') for n in names])
+    assert ok and len(rows) == len(names)
+    labels = [r[0] for r in rows]
+    assert labels[0] == 'conv1' and labels[1] == 'layer1.0 (block)' and labels[4] == 'layer2.0.conv1'
+    assert 'layer2.1.conv3+layer2.2.conv1' in labels and 'layer2.3.conv3+layer3.0.conv1' in labels and 'layer3.4.conv3+layer3.5.conv1' in labels
+    assert labels[-1] == 'layer4.2.conv3' and 'layer3.0.conv1' not in labels and 'layer3.1.conv1' in labels
 
 
 def test_prefetch_pieces_covers_every_clip_once_and_survives_failures():
