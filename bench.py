@@ -27,6 +27,12 @@ Extra objects on the line:
                 own onnxruntime CPU path cannot run here) timed on this box's host cores, batch 1 like
                 the reference (utils/inference_count.py:272), bounded to ~15 s; median (`value`) and best, with the CPU
                 model, the load average and torch's thread count beside them (a shared host: the figure moves with them)
+  config5       BASELINE.json configs[4] behind the headline (default command only): TSM_DTYPE_BF16, T = 16, 256 x 256, 64 clips
+                per GPU through the same call, with its own tuning, timed steps, `roofline` (dominant kernel against the
+                dense bf16 MFMA peak, forward_frac, PMC traffic, forward HBM rate) and `parity` (bf16-storage oracle); the
+                headline fields stay those of configs[1].  --no-config5 skips it (profiling runs).
+  build_id      tsm_build_id() of the library that ran == the sha of the source tree it was built from (the loader refuses
+                any other); `tune`: where the tile choices came from
   parity        the logits the TIMED steps produced (the output of the last timed step; what
                 utils/inference_count.py:273-275 would hand to the counter), checked on rank 0 AFTER the timed region
                 against the CPU oracle on a few of the timed clips: max |err| / logit scale against the bar of the parity
@@ -257,15 +263,21 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle check of the timed logits (profiling runs)')
     ap.add_argument('--no-alt', action='store_true', help='skip the second run in the other precision mode')
+    ap.add_argument('--no-config5', action='store_true',
+                    help='skip the BASELINE configs[4] leg (bf16, T=16, 256x256, 64 clips per GPU) behind the headline')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16x3', 'bf16'],
                     help='f32: exact-fp32 MFMA; bf16x3: split-bf16 storage, 3 bf16 MFMAs per product')
     ap.add_argument('--config', type=int, default=2, choices=[2, 5],
-                    help='BASELINE.json configuration: 2 = the headline defaults; 5 = T=16, 256x256, 64 clips per GPU, '
-                         'TSM_DTYPE_BF16 (sets --dtype/--batch/--segments/--size, skips the alt run and the CPU baseline)')
+                    help='BASELINE.json configuration of the HEADLINE fields: 2 = the defaults (configs[1], what the metric is '
+                         'quoted on; a configs[4] leg follows as the `config5` object); 5 = T=16, 256x256, 64 clips per GPU, '
+                         'TSM_DTYPE_BF16 as the headline itself (sets --dtype/--batch/--segments/--size, no alt / config5 / CPU legs)')
     args = ap.parse_args()
     if args.config == 5:
         args.dtype, args.batch, args.segments, args.size = 'bf16', 64, 16, 256
-        args.no_alt = args.no_cpu_baseline = True
+        args.no_alt = args.no_cpu_baseline = args.no_config5 = True
+    headline_defaults = (args.dtype, args.batch, args.segments, args.size) == ('f32', 32, 8, 224)
+    if not headline_defaults:
+        args.no_config5 = True       # the extra leg rides behind the driver's default command only
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # the driver's command form for N > 1 may come without a launcher: start the ranks ourselves, BEFORE torch
@@ -313,25 +325,39 @@ def main():
             name[0] = os.path.join(tempfile.mkdtemp(prefix='tsm_bench_'), 'tune_cache.txt')
         dist.broadcast_object_list(name, src=0, device=torch.device('cpu') if rehearsal else torch.device('cuda', local_rank))
         os.environ['TSM_TUNE_CACHE'] = name[0]
+        tune_note = 'rank 0 tuned in this job, the other ranks read its choices from a job-private TSM_TUNE_CACHE file'
+    elif 'TSM_TUNE_CACHE' not in os.environ:
+        # A single-GPU bench never reads the per-user tune cache: the first process to tune a build may have been a profiler
+        # run (serialised dispatches favour the one-launch forms) and its choices would silently be the headline's.
+        os.environ['TSM_TUNE_CACHE'] = 'off'
+        tune_note = 'tuned in this process (TSM_TUNE_CACHE=off: the per-user tune cache is neither read nor written)'
+    else:
+        tune_note = 'TSM_TUNE_CACHE=%s from the environment' % os.environ['TSM_TUNE_CACHE']
 
     from workoutdetector_amd.build import build_library
     if rank == 0:
         build_library()
     if collective:
         dist.barrier()
+    from workoutdetector_amd import _lib
     from workoutdetector_amd import distributed as tdist
     from workoutdetector_amd.distributed import all_gather_logits
     from workoutdetector_amd.engine import TsmEngine
+    from workoutdetector_amd.flops import layer_table
     tdist.set_force_collective(forced)
     from workoutdetector_amd.weights import make_state_dict
+    build_id = _lib.load().tsm_build_id().decode()
 
-    T, H, W, B = args.segments, args.size, args.size, args.batch
     sd = make_state_dict(0, 12)
-    gen = torch.Generator(device='cuda').manual_seed(rank)
-    clips = torch.randn(B, T, 3, H, W, device='cuda', generator=gen)
 
-    def run_mode(dtype, want_launch_times):
-        """W warm-up + K timed steps of one engine; returns wall seconds (max over ranks) and event timings."""
+    def make_clips(B, T, H, W):
+        gen = torch.Generator(device='cuda').manual_seed(rank)
+        return torch.randn(B, T, 3, H, W, device='cuda', generator=gen)
+
+    def run_mode(dtype, want_launch_times, geom, clips, parity_idx):
+        """W warm-up + K timed steps of one engine on `geom` = (T, H, W, B); returns a dict: wall seconds (max over ranks),
+        event timings, the tuner's tiles and the logits of the last timed step at `parity_idx`."""
+        T, H, W, B = geom
         if world > 1 and rank != 0:
             dist.barrier()       # rank 0 is tuning; its choices are in TSM_TUNE_CACHE when this returns
         eng = TsmEngine(num_class=12, num_segments=T, height=H, width=W, max_clips=B, device=local_rank,
@@ -368,12 +394,13 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         assert bool(torch.isfinite(out).all())
+        res = {'dtype': dtype, 'geom': geom}
         # the timed steps' own output, kept for the parity check below (a [world * B, 12] gather starts with this rank's rows)
-        timed_logits[dtype] = out[:B][parity_idx].detach().float().cpu().numpy()
+        res['timed_logits'] = out[:B][parity_idx].detach().float().cpu().numpy()
         # Per-launch durations of the timed forwards (events were recorded inside the timed region; reading
         # them here keeps the host syncs out of it).
-        per_launch = [eng.layer_times_ms(i) for i in range(n_timed)] if want_launch_times else []
-        step_ms[dtype] = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        res['per_launch'] = [eng.layer_times_ms(i) for i in range(n_timed)] if want_launch_times else []
+        res['step_ms'] = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
         eng.set_layer_timing(0)
         # Whole-forward kernel time (one HIP-event pair around all launches of a forward), outside the
         # wall-clock region because reading it synchronises.
@@ -385,9 +412,9 @@ def main():
         t_max = torch.tensor([elapsed], device='cuda')
         if collective:
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-            sm = step_ms[dtype]
+            sm = res['step_ms']
             mine = torch.tensor([[sm[len(sm) // 2], sorted(fwd_ev_ms)[len(fwd_ev_ms) // 2]]], device='cuda')
-            rank_ms[dtype] = all_gather_logits(mine).cpu().tolist()      # [world][step median, forward-kernel median]
+            res['rank_ms'] = all_gather_logits(mine).cpu().tolist()      # [world][step median, forward-kernel median]
             # the exchange step on its own ("all-gather us"), outside the timed region
             torch.cuda.synchronize()
             dist.barrier()
@@ -395,33 +422,21 @@ def main():
             for _ in range(20):
                 all_gather_logits(logits)
             torch.cuda.synchronize()
-            exchange_us[dtype] = 1e6 * (time.perf_counter() - t0) / 20
-        tiles = eng.conv_tiles(B)
+            res['exchange_us'] = 1e6 * (time.perf_counter() - t0) / 20
+        res['tiles'] = eng.conv_tiles(B)
         eng.close()
-        return float(t_max.item()), per_launch, sorted(fwd_ev_ms)[len(fwd_ev_ms) // 2], tiles
+        res['elapsed'] = float(t_max.item())
+        res['fwd_ms'] = sorted(fwd_ev_ms)[len(fwd_ev_ms) // 2]
+        return res
 
-    exchange_us, step_ms, rank_ms, timed_logits = {}, {}, {}, {}
-    parity_idx = sorted({0, B // 2, B - 1})[:PARITY_CLIPS]
-    elapsed, per_launch, fwd_ms, tiles = run_mode(args.dtype, True)
-    alt = None
-    if not args.no_alt:
-        alt_dtype = 'bf16x3' if args.dtype == 'f32' else 'f32'
-        alt_elapsed, _, alt_fwd_ms, _ = run_mode(alt_dtype, False)
-        alt = (alt_dtype, alt_elapsed, alt_fwd_ms)
-
-    parity = {}
-    if rank == 0 and not args.no_parity:
-        # Parity of what was TIMED, in this process: the CPU oracle on a few of the timed clips (outside the timed region)
-        want = oracle_logits(sd, clips[parity_idx].cpu(), T, list(timed_logits))
-        parity = {d: parity_of(g, want, d) for d, g in timed_logits.items()}
-        for d in parity:
-            parity[d]['clips'] = parity_idx
-    if rank == 0:
-        clips_total = B * world * args.steps
-        value = clips_total / elapsed
+    def roofline_of(res):
+        """The `roofline` object of one timed mode: the dominant kernel (the instantiation that runs most of the 3x3 time of
+        layer2-4) priced by its algorithmic flops and live launch durations, the whole forward beside it, PMC traffic from
+        the committed stamped passes."""
+        T, H, W, B = res['geom']
+        dtype, tiles, per_launch, fwd_ms = res['dtype'], res['tiles'], res['per_launch'], res['fwd_ms']
         gflop = flops_per_clip(T, H, W) / 1e9
         fwd_achieved = gflop * B / fwd_ms  # GFLOP / ms == TFLOP/s
-        from workoutdetector_amd.flops import layer_table
         frames = B * T
         table = {r['name']: r for r in layer_table(H, W)}
         dom = [r for r in table.values() if r['k'] == 3 and r['s'] >= 1 and not r['name'].startswith('layer1.')]
@@ -430,7 +445,7 @@ def main():
         # work it really does (its block's conv3 on top of the 3x3) and never mixed into the plain-3x3 group.
         groups = {}
         for r in dom:
-            kern, with_conv3 = kernel_of(tiles[r['name']], args.dtype, r['cout'], r['s'])
+            kern, with_conv3 = kernel_of(tiles[r['name']], dtype, r['cout'], r['s'])
             gf = 2.0 * r['macs'] * frames / 1e9
             if with_conv3:
                 gf += 2.0 * table[r['name'].replace('.conv2', '.conv3')]['macs'] * frames / 1e9
@@ -441,14 +456,82 @@ def main():
         dom_kernel, g = max(groups.items(), key=lambda kv: sum(kv[1]['ms']))
         dom_ms = g['ms']
         dom_gflop = sum(g['gflop']) / len(g['gflop'])
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
+        peak = PEAK_F32_MFMA_TFLOPS if dtype == 'f32' else PEAK_BF16_MFMA_TFLOPS
         peak_name = ('dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); the kernel executes 3 MFMA FLOPs per algorithmic FLOP'
-                     if args.dtype == 'bf16x3' else 'dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)' if args.dtype == 'bf16'
+                     if dtype == 'bf16x3' else 'dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)' if dtype == 'bf16'
                      else 'exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), dense')
         dom_avg_ms = sum(dom_ms) / len(dom_ms)
         achieved = dom_gflop / dom_avg_ms
         traffic_entry, traffic_stale = measured_traffic(B, T, H, W, dom_kernel)
-        sm = step_ms[args.dtype]
+        roof = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
+                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                'traffic': (traffic_entry or {}).get('hbm_bytes_per_launch'),
+                **({'traffic_stale': traffic_stale} if traffic_stale else {}),
+                'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/traffic.json)',
+                'kernel': dom_kernel + ' (3x3 convs of layer2-4%s, %d of 13 launches per forward)'
+                          % (', each with its block\'s conv3 + residual fused behind it'
+                             if dom_gflop > 1.01 * 2.0 * dom[0]['macs'] * frames / 1e9 else '',
+                             len(dom_ms) // len(per_launch)),
+                'gflop_per_launch': round(dom_gflop, 3), 'avg_launch_ms': round(dom_avg_ms, 4),
+                'launches_timed': len(dom_ms),
+                'peak_name': peak_name,
+                'forward_achieved': round(fwd_achieved, 2),
+                'forward_frac': round(fwd_achieved / peak, 4),
+                'forward_gflop': round(gflop * B, 3), 'forward_kernel_ms': round(fwd_ms, 4)}
+        if traffic_entry and traffic_entry.get('forward_hbm_bytes'):
+            # whole-forward HBM rate from the committed PMC passes (bytes) over the live forward time: the second
+            # roofline SURVEY 8d asks for beside the MFMA one (matters for the bf16 formats)
+            gbs = traffic_entry['forward_hbm_bytes'] / 1e9 / (fwd_ms / 1e3)
+            roof.update({'forward_hbm_bytes': traffic_entry['forward_hbm_bytes'], 'forward_hbm_gbs': round(gbs, 1),
+                         'forward_hbm_frac': round(gbs / PEAK_HBM_GBS, 4), 'hbm_peak_gbs': PEAK_HBM_GBS})
+        return roof
+
+    def workload_of(geom, dtype, config_index):
+        T, H, W, B = geom
+        return (f'TSM-R50 {T}-seg {H}x{W} 12-class inference, batch {B} clips per GPU, ' +
+                '%s NHWC, device-resident input (BASELINE.json configs[%d])' % (dtype, config_index))
+
+    geom = (args.segments, args.size, args.size, args.batch)
+    T, H, W, B = geom
+    clips = make_clips(B, T, H, W)
+    parity_idx = sorted({0, B // 2, B - 1})[:PARITY_CLIPS]
+    main_res = run_mode(args.dtype, True, geom, clips, parity_idx)
+    runs = {args.dtype: main_res}
+    alt_res = None
+    if not args.no_alt:
+        alt_dtype = 'bf16x3' if args.dtype == 'f32' else 'f32'
+        alt_res = runs[alt_dtype] = run_mode(alt_dtype, False, geom, clips, parity_idx)
+
+    parity = {}
+    if rank == 0 and not args.no_parity:
+        # Parity of what was TIMED, in this process: the CPU oracle on a few of the timed clips (outside the timed region)
+        want = oracle_logits(sd, clips[parity_idx].cpu(), T, list(runs))
+        parity = {d: parity_of(r['timed_logits'], want, d) for d, r in runs.items()}
+        for d in parity:
+            parity[d]['clips'] = parity_idx
+    del clips
+
+    # BASELINE configs[4] behind the headline: the stress shape (bf16 weights + activations, T = 16, 256 x 256, 64 clips per
+    # GPU) through the same call (utils/inference_count.py:273-275 / models/tsm.py:409-419), its own tuning, the same
+    # steps / warm-up, its own roofline and its own parity check (the bf16-storage oracle, on the first and the last clip).
+    c5_res, c5_parity = None, None
+    if not args.no_config5:
+        geom5 = (16, 256, 256, 64)
+        clips5 = make_clips(64, 16, 256, 256)
+        idx5 = [0, 63]
+        c5_res = run_mode('bf16', True, geom5, clips5, idx5)
+        if rank == 0 and not args.no_parity:
+            want5 = oracle_logits(sd, clips5[idx5].cpu(), 16, ['bf16'])
+            c5_parity = parity_of(c5_res['timed_logits'], want5, 'bf16')
+            c5_parity['clips'] = idx5
+        del clips5
+
+    if rank == 0:
+        elapsed = main_res['elapsed']
+        clips_total = B * world * args.steps
+        value = clips_total / elapsed
+        gflop = flops_per_clip(T, H, W) / 1e9
+        sm = main_res['step_ms']
         if rehearsal:
             parallelism = (f'REHEARSAL: {world} ranks sharing cuda:0, gloo all-gather through host memory -- control flow '
                            'only, not a measurement')
@@ -468,33 +551,14 @@ def main():
                                 'design decisions must be read against'},
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'TSM-R50 {T}-seg {H}x{W} 12-class inference, batch {B} clips per GPU, ' +
-                                   '%s NHWC, device-resident input (BASELINE.json configs[%d])' % (args.dtype, 4 if args.config == 5 else 1),
+            'config': {'workload': workload_of(geom, args.dtype, 4 if args.config == 5 else 1),
                        'clips_per_gpu': B, 'num_segments': T, 'height': H, 'width': W, 'num_class': 12,
                        'weights': 'seeded random init (no trained weights offline)',
                        'parallelism': parallelism},
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': peak,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                         'traffic': (traffic_entry or {}).get('hbm_bytes_per_launch'),
-                         **({'traffic_stale': traffic_stale} if traffic_stale else {}),
-                         'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/traffic.json)',
-                         'kernel': dom_kernel + ' (3x3 convs of layer2-4%s, %d of 13 launches per forward)'
-                                   % (', each with its block\'s conv3 + residual fused behind it'
-                                      if dom_gflop > 1.01 * 2.0 * dom[0]['macs'] * frames / 1e9 else '',
-                                      len(dom_ms) // len(per_launch)),
-                         'gflop_per_launch': round(dom_gflop, 3), 'avg_launch_ms': round(dom_avg_ms, 4),
-                         'launches_timed': len(dom_ms),
-                         'peak_name': peak_name,
-                         'forward_achieved': round(fwd_achieved, 2),
-                         'forward_frac': round(fwd_achieved / peak, 4),
-                         'forward_gflop': round(gflop * B, 3), 'forward_kernel_ms': round(fwd_ms, 4)},
+            'roofline': roofline_of(main_res),
+            'build_id': build_id,
+            'tune': tune_note,
         }
-        if traffic_entry and traffic_entry.get('forward_hbm_bytes'):
-            # whole-forward HBM rate from the committed PMC passes (bytes) over the live forward time: the second
-            # roofline SURVEY 8d asks for beside the MFMA one (matters for the bf16 formats)
-            gbs = traffic_entry['forward_hbm_bytes'] / 1e9 / (fwd_ms / 1e3)
-            line['roofline'].update({'forward_hbm_gbs': round(gbs, 1), 'forward_hbm_frac': round(gbs / PEAK_HBM_GBS, 4),
-                                     'hbm_peak_gbs': PEAK_HBM_GBS})
         if parity:
             line['parity'] = parity[args.dtype]
         if rehearsal:
@@ -502,14 +566,14 @@ def main():
         if collective:
             line['exchange'] = {'collective': 'all_gather_into_tensor of f32[%d, 12] per rank (backend %s%s)'
                                               % (B, backend, ' = RCCL' if backend == 'nccl' else ': NOT RCCL, rehearsal'),
-                                'avg_us': round(exchange_us[args.dtype], 1),
-                                'per_rank_step_ms_median': [round(r[0], 4) for r in rank_ms[args.dtype]],
-                                'per_rank_forward_kernel_ms_median': [round(r[1], 4) for r in rank_ms[args.dtype]],
+                                'avg_us': round(main_res['exchange_us'], 1),
+                                'per_rank_step_ms_median': [round(r[0], 4) for r in main_res['rank_ms']],
+                                'per_rank_forward_kernel_ms_median': [round(r[1], 4) for r in main_res['rank_ms']],
                                 'tune_cache': 'one TSM_TUNE_CACHE file for all ranks: rank 0 tunes, the others read its '
                                               'tile choices' if world > 1 else 'single rank',
                                 'note': 'back-to-back latency of the only data-path collective, measured outside the timed steps'}
-        if alt is not None:
-            a_dtype, a_elapsed, a_fwd = alt
+        if alt_res is not None:
+            a_dtype, a_elapsed, a_fwd = alt_res['dtype'], alt_res['elapsed'], alt_res['fwd_ms']
             line['alt_precision'] = {
                 'dtype': a_dtype, 'value': None if rehearsal else round(clips_total / a_elapsed, 2), 'unit': 'clips/s',
                 'ms_per_step': round(1e3 * a_elapsed / args.steps, 4), 'forward_kernel_ms': round(a_fwd, 4),
@@ -521,12 +585,34 @@ def main():
                         if a_dtype == 'bf16x3' else 'exact-fp32 MFMA mode of the same engine'}
             if a_dtype in parity:
                 line['alt_precision']['parity'] = parity[a_dtype]
+        if c5_res is not None:
+            c5_total = 64 * world * args.steps
+            c5_sm = c5_res['step_ms']
+            line['config5'] = {
+                'metric': 'clips/sec (16x3x256x256 TSM-R50)',
+                'value': None if rehearsal else round(c5_total / c5_res['elapsed'], 2), 'unit': 'clips/s',
+                'dtype': 'bf16', 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': round(1e3 * c5_res['elapsed'] / args.steps, 4),
+                'step_ms': {'min': round(c5_sm[0], 4), 'median': round(c5_sm[len(c5_sm) // 2], 4), 'max': round(c5_sm[-1], 4)},
+                'config': {'workload': workload_of((16, 256, 256, 64), 'bf16', 4), 'clips_per_gpu': 64, 'num_segments': 16,
+                           'height': 256, 'width': 256, 'num_class': 12},
+                'roofline': roofline_of(c5_res),
+                'note': 'BASELINE.json configs[4] (the MFMA / HBM stress shape) on this rank count: its own engine, tuning, '
+                        'timed steps and parity check, run behind the headline in the same process; NOT the metric the '
+                        'headline `value` is quoted on'}
+            if collective:
+                line['config5']['exchange_avg_us'] = round(c5_res['exchange_us'], 1)
+            if c5_parity is not None:
+                line['config5']['parity'] = c5_parity
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(sd, T, H, W)
         print(json.dumps(line), flush=True)
         bad = [d for d, q in parity.items() if not q['ok']]
+        if c5_parity is not None and not c5_parity['ok']:
+            bad.append('config5/bf16')
         if bad:
-            raise SystemExit(f'parity check of the timed logits FAILED for {bad}: {[parity[d] for d in bad]}')
+            raise SystemExit(f'parity check of the timed logits FAILED for {bad}: '
+                             f'{[parity[d] if d in parity else c5_parity for d in bad]}')
     if collective:
         dist.barrier()
         dist.destroy_process_group()

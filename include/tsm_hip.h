@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define TSM_ABI_VERSION 6 /* 6: tsm_tune, per-user default tune cache; 5: tsm_gather_clips; 4: tsm_scores_to_states; tile codes lost the tail field; TSM_* variables read in tsm_create only */
+#define TSM_ABI_VERSION 7 /* 7: tsm_build_id, tsm_trace_launches / tsm_launch_trace; 6: tsm_tune, per-user default tune cache; 5: tsm_gather_clips; 4: tsm_scores_to_states; tile codes lost the tail field; TSM_* variables read in tsm_create only */
 
 typedef enum tsm_status {
   TSM_OK = 0,
@@ -112,6 +112,24 @@ typedef struct tsm_config {
 typedef struct tsm_engine tsm_engine;
 
 int tsm_abi_version(void);
+
+/* The identity of the SOURCE this binary was built from: the first 16 hex digits of the sha256 over csrc/ (file names,
+ * contents, per-file compiler options) and the extra compiler definitions of the build -- what
+ * workoutdetector_amd/build.py::build_id() computes from the tree.  The library is git-ignored and travels prebuilt, so
+ * the Python host refuses one whose id is not the tree's (workoutdetector_amd/_lib.py) and bench.py prints it; it also
+ * keys the tune cache.  A hand build without -DTSM_BUILD_ID reports its compile time stamp.
+ * (No counterpart in the reference: a Python package cannot be stale against itself.) */
+const char *tsm_build_id(void);
+
+/* Launch trace of the CALLING THREAD (parity tests: "did the kernel under test really run?").  tsm_trace_launches(1)
+ * clears the thread's trace and starts recording one line per kernel launch this library makes from that thread -- the
+ * kernel's name as rocprofv3 would print it up to template-argument spelling, e.g. "bneck_ws_kernel<256, true, true>" or
+ * "conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16> [BM = 64, BN = 64, ...]"; tsm_trace_launches(0) stops.
+ * tsm_launch_trace copies the newline-separated trace (NUL-terminated) into buf when cap suffices and always returns the
+ * bytes needed.  Off by default; per thread, like the engine-less error message: no process-global state.
+ * (No counterpart in the reference: onnxruntime's session.run is opaque, utils/inference_count.py:273-275.) */
+int tsm_trace_launches(int32_t on);
+int64_t tsm_launch_trace(char *buf, int64_t cap);
 
 /* Engine lifetime ------------------------------------------------------------------------- */
 int tsm_create(const tsm_config *cfg, tsm_engine **out);

@@ -7,6 +7,35 @@ def make_input(seed, b, t, h, w):
     return rng.standard_normal((b, t, 3, h, w)).astype(np.float32)
 
 
+# ---- "the kernel under test is the one that ran" ---------------------------------------------------------------------
+# (workoutdetector_amd.engine.launch_trace records the library's kernel launches of the calling thread; a forced kernel
+#  form that silently fell back would otherwise make every "bit-identical" comparison trivially true)
+IGEMM_TILE_DIMS = {'64x64': (64, 64, 2, 2), '128x64': (128, 64, 2, 2), '128x128': (128, 128, 2, 2),
+                   '128x128w8': (128, 128, 4, 2), '32x32': (32, 32, 1, 1)}
+TILE_KERNELS = {'256x256': ('conv_bf16_256_kernel<',), '256x256p': ('conv_bf16_256p_kernel<',),
+                'ws': ('conv3x3_ws_kernel<', 'conv3x3_ws128_kernel<', 'conv1x1_ws_kernel<', 'conv1x1_wsn_kernel<')}
+
+
+def ran_tile(trace, tile):
+    """Did a launch of the kernel family behind TSM_CONV_TILE=`tile` appear in the trace?"""
+    if tile in IGEMM_TILE_DIMS:
+        want = '[BM = %d, BN = %d, WGM = %d, WGN = %d,' % IGEMM_TILE_DIMS[tile]
+        return any(k.startswith('conv_igemm<') and want in k for k in trace.kernels)
+    return any(trace.ran(p) for p in TILE_KERNELS[tile])
+
+
+def assert_ran(trace, prefix, what=''):
+    assert trace.ran(prefix), f'{what}: no `{prefix}` launch; the trace holds {sorted(set(trace.kernels))}'
+
+
+def assert_not_ran(trace, prefix, what=''):
+    assert not trace.ran(prefix), f'{what}: `{prefix}` ran although it must not: {sorted(set(trace.kernels))}'
+
+
+def assert_ran_tile(trace, tile, what=''):
+    assert ran_tile(trace, tile), f'{what}: TSM_CONV_TILE={tile} did not run its kernel; the trace holds {sorted(set(trace.kernels))}'
+
+
 def assert_close(got, want, rtol, atol_scale=1e-4, what=''):
     """|got - want| <= rtol * |want| + atol_scale * max|want|  (elementwise), fp32 tolerance."""
     got = np.asarray(got, dtype=np.float64)

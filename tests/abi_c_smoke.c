@@ -169,6 +169,8 @@ int main(int argc, char **argv) {
   tsm_config cfg;
   tsm_engine *e = NULL;
   if (tsm_abi_version() != TSM_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 2; }
+  if (strlen(tsm_build_id()) == 0) { fprintf(stderr, "no build id\n"); return 14; }
+  if (tsm_launch_trace(NULL, 0) != 1) { fprintf(stderr, "launch trace not empty by default\n"); return 15; }
   memset(&cfg, 0, sizeof cfg);
   cfg.struct_size = 4;  /* wrong on purpose */
   if (tsm_create(&cfg, &e) != TSM_ERR_INVALID_ARG || e != NULL) { fprintf(stderr, "struct_size not checked\n"); return 3; }
@@ -191,12 +193,21 @@ int main(int argc, char **argv) {
     const size_t n = (size_t)8 * 3 * 64 * 64;
     float *clip = (float *)malloc(n * sizeof(float)), logits[12];
     for (size_t i = 0; i < n; ++i) clip[i] = (float)(i % 17) - 8.0f;
+    char trace[16384];
+    tsm_trace_launches(1);
     if (tsm_forward(e, clip, TSM_MEM_HOST, TSM_LAYOUT_NTCHW, 1, logits, NULL)) { fprintf(stderr, "forward: %s\n", tsm_last_error(e)); return 9; }
+    tsm_trace_launches(0);
+    /* the trace names what ran: the pool-fused fp32 stem reading the reference layout, implicit-GEMM convs, the head */
+    if (tsm_launch_trace(trace, (int64_t)sizeof trace) > (int64_t)sizeof trace || strstr(trace, "stem_pool_f32_kernel<true>") == NULL ||
+        strstr(trace, "conv_igemm<") == NULL || strstr(trace, "head_fc_kernel") == NULL) {
+      fprintf(stderr, "launch trace: %s\n", trace);
+      return 16;
+    }
     for (int i = 0; i < 12; ++i)
       if (logits[i] != 0.5f * (float)i - 1.0f) { fprintf(stderr, "logit %d = %g\n", i, logits[i]); return 10; }
     free(clip);
   }
   tsm_destroy(e);
-  printf("abi_c_smoke: forward ok\n");
+  printf("abi_c_smoke: forward ok (build %s)\n", tsm_build_id());
   return 0;
 }

@@ -48,8 +48,75 @@ def test_no_kernel_stub_is_missing_from_the_library():
 
 def test_abi_version_and_config_layout(lib):
     from workoutdetector_amd import _lib
-    assert lib.tsm_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.tsm_abi_version() == _lib.ABI_VERSION == 7
     assert ctypes.sizeof(_lib.TsmConfig) == 40          # 10 x int32, matches struct tsm_config
+
+
+def test_library_carries_the_build_id_of_this_tree(lib):
+    """tsm_build_id() == build.build_id() (sha of csrc/ + the ABI header + per-file options [+ TSM_BUILD_DEFS]) == the tag found
+    in the FILE without loading it: the three views a loader, a bench line and an incremental build use."""
+    from workoutdetector_amd import build
+    have = lib.tsm_build_id().decode()
+    assert have == build.build_id() == build.library_build_id() and len(have) == 16 and int(have, 16) >= 0
+    assert not build.is_stale()
+
+
+def test_a_library_built_from_other_sources_is_refused(tmp_path):
+    """The .so is git-ignored and travels prebuilt: _lib.load() must refuse one whose build id is not the tree's (it would be
+    tested and benchmarked silently), and build.is_stale() must see it whatever the modification times say.  Done on a COPY
+    of the library whose embedded id is patched, loaded in a child process (TSM_LIB_PATH would accept an A/B build on
+    purpose, so the child points LIB_PATH at the copy by hand)."""
+    import shutil
+    import sys
+    from workoutdetector_amd import build
+    fake = str(tmp_path / 'libtsm_hip.so')
+    shutil.copy(build.LIB_PATH, fake)
+    blob = open(fake, 'rb').read()
+    tag = b'tsm-build-id:' + build.build_id().encode()
+    assert blob.count(tag) >= 1
+    open(fake, 'wb').write(blob.replace(tag, b'tsm-build-id:' + b'0123456789abcdef'))
+    os.utime(fake, None)                                    # newer than every source: the mtime rule would have kept it
+    assert build.library_build_id(fake) == '0123456789abcdef' != build.build_id()
+    code = ('import sys; sys.path.insert(0, %r)\n'
+            'from workoutdetector_amd import build, _lib\n'
+            'build.LIB_PATH = _lib.LIB_PATH = %r\n'
+            'assert build.is_stale()\n'
+            'try:\n'
+            '    _lib.load()\n'
+            'except ImportError as e:\n'
+            '    assert "built from other sources" in str(e) and "0123456789abcdef" in str(e), e\n'
+            '    print("refused")\n') % (ROOT, fake)
+    env = {k: v for k, v in os.environ.items() if k not in ('TSM_LIB_PATH', 'TSM_BUILD_DEFS')}
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and 'refused' in out.stdout, out.stderr
+
+
+def test_ab_build_definitions_change_the_build_id(monkeypatch):
+    """two variant libraries of one source (TSM_BUILD_DEFS) must not share tune-cache lines: the id hashes the
+    definitions too."""
+    from workoutdetector_amd import build
+    plain = build.build_id()
+    monkeypatch.setenv('TSM_BUILD_DEFS', '-DTSM_OUT_AUX=16')
+    a = build.build_id()
+    monkeypatch.setenv('TSM_BUILD_DEFS', '-DTSM_OUT_AUX=2')
+    b = build.build_id()
+    assert len({plain, a, b}) == 3 and plain == build.csrc_sha16()
+
+
+def test_launch_trace_is_off_by_default_and_per_thread(lib):
+    """tsm_trace_launches / tsm_launch_trace without a GPU: nothing launches, so the trace is empty; the size protocol
+    (returns the bytes needed, copies when the buffer suffices) and the per-thread state are checked here, the contents
+    on the GPU (tests/test_bf16_gpu.py, test_engine_gpu.py: "the kernel under test is the one that ran")."""
+    import threading
+    assert lib.tsm_launch_trace(None, 0) == 1                     # just the terminator
+    assert lib.tsm_trace_launches(1) == 0
+    buf = ctypes.create_string_buffer(4)
+    assert lib.tsm_launch_trace(buf, 4) == 1 and buf.value == b''
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.tsm_launch_trace(None, 0)))
+    t.start(); t.join()
+    assert seen == [1]
+    assert lib.tsm_trace_launches(0) == 0
 
 
 def test_create_rejects_bad_config_before_touching_the_gpu(lib):

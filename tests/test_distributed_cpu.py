@@ -207,6 +207,60 @@ def _dataset_global_failing_worker(rank, world, root, out_dir):
         open(os.path.join(out_dir, f'raised{rank}'), 'w').write('peer')
 
 
+def _dataset_global_plan_failing_worker(rank, world, root, out_dir):
+    """Rank 2's frame counter raises while the plan is laid out (before the FIRST exchange): every rank must come out of
+    inference_dataset with an exception instead of blocking in the plan-checksum all-gather."""
+    from tests._stub import StubModel
+    from workoutdetector_amd import inference_count as ic
+
+    def counter(path):
+        if rank == 2:
+            raise OSError('no index for ' + os.path.basename(path))
+        return int(np.load(path, mmap_mode='r').shape[0])
+
+    try:
+        ic.inference_dataset(StubModel(), ['test'], out_dir, checkpoint='stub', data_root=root, batch_clips=4, frame_counter=counter)
+    except OSError as exc:
+        assert rank == 2 and 'no index' in str(exc)
+        open(os.path.join(out_dir, f'raised{rank}'), 'w').write('own')
+    except RuntimeError as exc:
+        assert rank != 2 and 'rank(s) [2] failed while planning' in str(exc), str(exc)
+        open(os.path.join(out_dir, f'raised{rank}'), 'w').write('peer')
+
+
+def _dataset_global_warmup_failing_worker(rank, world, root, out_dir):
+    """Rank 0's model fails in warmup() (a tsm_tune HIP error / OOM in the real engine) -- after the plan exchange, before the
+    loop: it must ride the status row of the final exchange like a failure inside the loop."""
+    from tests._stub import StubModel
+    from workoutdetector_amd import inference_count as ic
+
+    class ColdFail(StubModel):
+        def warmup(self, sizes):
+            if rank == 0:
+                raise MemoryError('tune scratch')
+            return self
+
+    # (the warm-up only runs for a model on a device: give the stub one the way _engine_device reads it)
+    orig = ic._engine_device
+    ic._engine_device = lambda m: None
+    try:
+        model = ColdFail()
+        run_global = ic._run_global
+
+        def run_with_warm(model_, items, mine, counts, make_pieces, warm, *rest):
+            return run_global(model_, items, mine, counts, make_pieces, (lambda: model_.warmup([4])), *rest)
+        ic._run_global = run_with_warm
+        ic.inference_dataset(model, ['test'], out_dir, checkpoint='stub', data_root=root, batch_clips=4)
+    except MemoryError:
+        assert rank == 0
+        open(os.path.join(out_dir, f'raised{rank}'), 'w').write('own')
+    except RuntimeError as exc:
+        assert rank != 0 and 'rank(s) [0] failed' in str(exc), str(exc)
+        open(os.path.join(out_dir, f'raised{rank}'), 'w').write('peer')
+    finally:
+        ic._engine_device = orig
+
+
 def test_global_sharding_failure_on_one_rank_reaches_every_rank(tmp_path, golden_dir):
     """with no collective inside the loop, a rank that raises must still enter the final exchange (error marker
     in the video table) -- the other ranks then raise too instead of waiting for ever; and ranks whose shard plans differ
@@ -227,6 +281,14 @@ def test_global_sharding_failure_on_one_rank_reaches_every_rank(tmp_path, golden
     _spawn(_dataset_global_failing_worker, str(root), out_dir, world=3)
     assert sorted(f for f in os.listdir(out_dir) if f.startswith('raised')) == ['raised0', 'raised1', 'raised2']
     assert open(os.path.join(out_dir, 'raised1')).read() == 'own' and open(os.path.join(out_dir, 'raised0')).read() == 'peer'
+    # ... a failure BEFORE the first exchange (planning) and one between the exchanges but outside the loop (warm-up)
+    for worker, owner_rank in ((_dataset_global_plan_failing_worker, 2), (_dataset_global_warmup_failing_worker, 0)):
+        out2 = str(tmp_path / worker.__name__)
+        os.makedirs(out2)
+        _spawn(worker, str(root), out2, world=3)
+        assert sorted(f for f in os.listdir(out2) if f.startswith('raised')) == ['raised0', 'raised1', 'raised2'], worker.__name__
+        for r in range(3):
+            assert open(os.path.join(out2, f'raised{r}')).read() == ('own' if r == owner_rank else 'peer'), (worker.__name__, r)
 
 
 def _dataset_global_anon_worker(rank, world, root, out_dir):

@@ -130,7 +130,8 @@ def test_error_behaviour(hip_lib, sd0, engine224):
 def test_autotuned_tiles_are_bitwise_invariant(hip_lib, sd0, monkeypatch):
     """The engine picks a conv tile shape per layer by timing; every shape accumulates each output in the
     same k order, so logits must not depend on the choice (heuristic vs tuned vs each forced shape)."""
-    from workoutdetector_amd.engine import TsmEngine
+    from workoutdetector_amd.engine import TsmEngine, launch_trace
+    from tests._util import IGEMM_TILE_DIMS, assert_ran_tile
     x = make_input(21, 3, 8, 96, 96)
     outs = {}
     for name, env in [('tuned', {}), ('heuristic', {'TSM_AUTOTUNE': '0'}),
@@ -143,9 +144,12 @@ def test_autotuned_tiles_are_bitwise_invariant(hip_lib, sd0, monkeypatch):
             monkeypatch.setenv(k, v)
         eng = TsmEngine(height=96, width=96, max_clips=3, state_dict=sd0)
         outs[name] = eng.run(None, {'input': x})[0]
-        again = eng.run(None, {'input': x})[0]          # second call runs from the tile cache
+        with launch_trace() as tr:
+            again = eng.run(None, {'input': x})[0]          # second call runs from the tile cache
         assert np.array_equal(outs[name], again)
         eng.close()
+        if name in IGEMM_TILE_DIMS:       # the forced shape ran (wherever it is valid; the rest keeps the heuristic shape)
+            assert_ran_tile(tr, name, f'f32 engine forced onto {name}')
     assert np.array_equal(outs['tuned'], outs['heuristic'])
     assert np.array_equal(outs['tuned'], outs['64x64']) and np.array_equal(outs['tuned'], outs['32x32'])
     assert np.array_equal(outs['tuned'], outs['128x128w8'])
@@ -266,7 +270,7 @@ def test_c_program_runs_the_device_pipeline(hip_lib, tmp_path):
 ])
 def test_unusual_configurations_against_oracle(hip_lib, monkeypatch, capsys, dtype, t, div, h, w, ncls, rtol):
     """Segment counts, shift_div, class counts and aspect ratios other than the headline's, vs the CPU oracle."""
-    from workoutdetector_amd.engine import TsmEngine
+    from workoutdetector_amd.engine import TsmEngine, launch_trace
     from workoutdetector_amd.weights import make_state_dict, to_torch
     dtype, _, force = dtype.partition('+')
     if force == 'fused':
@@ -278,8 +282,14 @@ def test_unusual_configurations_against_oracle(hip_lib, monkeypatch, capsys, dty
     eng = TsmEngine(num_class=ncls, num_segments=t, height=h, width=w, shift_div=div, max_clips=3, state_dict=sd,
                     dtype=dtype)
     x = make_input(100 + t, 3, t, h, w)
-    got = eng.run(None, {'input': x})[0]
+    with launch_trace() as tr:
+        got = eng.run(None, {'input': x})[0]
     eng.close()
+    if force == 'fused':     # conv2 + conv3 as one launch: conv23_fused_kernel (fp32 / split-bf16)
+        assert tr.ran('conv23_fused_kernel<64,') and tr.ran('conv23_fused_kernel<128,'), sorted(set(tr.kernels))
+    elif force:
+        from tests._util import assert_ran_tile
+        assert_ran_tile(tr, force, f'{dtype} engine forced onto {force}')
     want = tsm_oracle.tsm_forward(to_torch(sd), torch.from_numpy(x), n_segment=t, shift_div=div).numpy()
     assert got.shape == (3, ncls)
     if dtype == 'bf16':      # its own oracle: the bf16-storage restatement (bar = 1e-2 of the logit scale, same arg-max)
@@ -295,7 +305,7 @@ def test_split_k_is_bitwise_identical_to_whole_k(hip_lib, sd0, monkeypatch):
     """Long-K fp32 layers accumulate K in fixed segments (ConvParams::kseg_len), so the split-K launch form (one
     workgroup per tile and segment + ordered reduction, what the tuner picks at small batch) must reproduce the
     whole-K form bit for bit, on both tile shapes that implement it."""
-    from workoutdetector_amd.engine import TsmEngine
+    from workoutdetector_amd.engine import TsmEngine, launch_trace
     x = make_input(31, 2, 8, 96, 96)
     outs = {}
     for name, env in [('whole 64x64', {'TSM_AUTOTUNE': '1', 'TSM_CONV_CODE': '3'}),
@@ -307,7 +317,15 @@ def test_split_k_is_bitwise_identical_to_whole_k(hip_lib, sd0, monkeypatch):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = TsmEngine(height=96, width=96, max_clips=2, state_dict=sd0)
-        outs[name] = eng.run(None, {'input': x})[0]
+        with launch_trace() as tr:
+            outs[name] = eng.run(None, {'input': x})[0]
+        # the forced form ran: one splitk_reduce launch behind every segmented layer (tile shape as forced), none in the whole-K form
+        if name.startswith('split'):
+            assert tr.ran('splitk_reduce_kernel'), sorted(set(tr.kernels))
+            dims = '[BM = 64, BN = 64,' if '64x64' in name else '[BM = 32, BN = 32,'
+            assert any(k.startswith('conv_igemm<') and 'true>' in k.split('[')[0] and dims in k for k in tr.kernels), sorted(set(tr.kernels))
+        elif name.startswith('whole'):
+            assert not tr.ran('splitk_reduce_kernel'), sorted(set(tr.kernels))
         tap = eng.forward_tap(x, 'layer4.1')
         outs[name + ' tap'] = tap
         if name == 'tuned':     # 2 clips of 96x96: layer3/4 have a handful of tiles, so split-K normally wins the timing
@@ -416,16 +434,22 @@ def test_fused_conv2_conv3_equals_the_separate_kernels_bitwise(hip_lib, sd0, mon
     (90x70: 414 / 108 pixels per frame) and the segmented-K layer2 convs.  bf16: the weight-stationary form
     (conv3x3_ws_kernel<true>, layer1.1-2 only; the mid tensor stays in registers); 256x256 with 3 clips = 384 tiles,
     more than one per persistent workgroup."""
-    from workoutdetector_amd.engine import TsmEngine
+    from workoutdetector_amd.engine import TsmEngine, launch_trace
     x = make_input(80 + h, b, 8, h, w)
     got = {}
     for flag in ('1', '0'):
         monkeypatch.setenv('TSM_FUSE_CONV23', flag)
+        monkeypatch.setenv('TSM_FUSE_BLOCK', '0')    # (bf16: the whole-block kernel would otherwise take layer1 from both arms)
         eng = TsmEngine(height=h, width=w, max_clips=b, state_dict=sd0, dtype=dtype)
-        got[flag] = [eng.run(None, {'input': x})[0]] + [eng.forward_tap(x, s) for s in ('layer1.1', 'layer1.2', 'layer2.3')]
-        if flag == '1':
-            tiles = eng.conv_tiles(b)
+        with launch_trace() as tr:
+            got[flag] = [eng.run(None, {'input': x})[0]] + [eng.forward_tap(x, s) for s in ('layer1.1', 'layer1.2', 'layer2.3')]
         eng.close()
+        # what RAN: bf16 -> conv3x3_ws_kernel<true> (layer1.1-2); fp32 / split-bf16 -> conv23_fused_kernel<64 | 128, X3>
+        fused_kernels = ['conv3x3_ws_kernel<true>'] if dtype == 'bf16' else \
+            ['conv23_fused_kernel<%d, %s>' % (c, 'true' if dtype == 'bf16x3' else 'false') for c in (64, 128)]
+        for kern in fused_kernels:
+            assert tr.ran(kern) == (flag == '1'), (flag, kern, sorted(set(tr.kernels)))
+    monkeypatch.delenv('TSM_FUSE_BLOCK')
     for a, c in zip(got['1'], got['0']):
         assert np.array_equal(a, c)
     monkeypatch.delenv('TSM_FUSE_CONV23')

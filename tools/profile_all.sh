@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSM_TUNE_CACHE=off   # a profiler run never writes (or reads) the per-user tune cache: serialised dispatches favour the one-launch forms
 # One call that refreshes every judged profile artefact of a round on the GPU box (run from the repo root):
 #   bash tools/profile_all.sh r02        -> gpurun_out/<tag>_*  (copy the summaries you want judged into profiles/)
 # Separate rocprofv3 passes for --stats / FETCH_SIZE / WRITE_SIZE / SQ counters (never combined with trace domains).
@@ -11,7 +12,7 @@ O=$R/gpurun_out
 run_stats() {  # name, frames, size, bench args...
   local name=$1 frames=$2 size=$3; shift 3
   (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_${name}_stats -o run -- \
-     python3 $R/bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline --no-parity "$@" > $O/${tag}_${name}_bench_line.json 2> $O/${tag}_${name}_stats.log)
+     python3 $R/bench.py --steps 20 --warmup 5 --no-alt --no-config5 --no-cpu-baseline --no-parity "$@" > $O/${tag}_${name}_bench_line.json 2> $O/${tag}_${name}_stats.log)
   python3 tools/layer_times.py $O/${tag}_${name}_stats/run_kernel_trace.csv $frames $size > $O/${tag}_${name}_per_layer.txt
   cp $O/${tag}_${name}_stats/run_kernel_stats.csv $O/${tag}_${name}_kernel_stats.csv
   tail -1 $O/${tag}_${name}_per_layer.txt

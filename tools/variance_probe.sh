@@ -1,4 +1,5 @@
 #!/bin/bash
+export TSM_TUNE_CACHE=off   # a profiler run never writes (or reads) the per-user tune cache: serialised dispatches favour the one-launch forms
 # conv3x3_ws_kernel<true> placement variance: N fresh processes, each timing the fused launch (kernel
 # trace) AND collecting the L2 <-> fabric counters per TCC channel in the same run, so a slow-regime process can be laid
 # beside a fast one:   bash tools/variance_probe.sh <n_processes> [tag]   -> gpurun_out/variance_<tag>/p<i>/

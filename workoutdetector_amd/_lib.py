@@ -6,9 +6,9 @@ import ctypes as C
 import os
 from typing import Optional
 
-from .build import LIB_PATH
+from .build import LIB_PATH, build_id
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 MEM_HOST, MEM_DEVICE = 0, 1
 LAYOUT_NTCHW, LAYOUT_NTHWC, LAYOUT_NTHWC4, LAYOUT_NTHWC8S, LAYOUT_NTHWC8B = 0, 1, 2, 3, 4
@@ -32,7 +32,7 @@ class TsmError(RuntimeError):
         self.status = status
 
 
-EXPORTS = ('tsm_abi_version', 'tsm_create', 'tsm_destroy', 'tsm_last_error', 'tsm_set_tensor', 'tsm_finalize',
+EXPORTS = ('tsm_abi_version', 'tsm_build_id', 'tsm_trace_launches', 'tsm_launch_trace', 'tsm_create', 'tsm_destroy', 'tsm_last_error', 'tsm_set_tensor', 'tsm_finalize',
            'tsm_forward', 'tsm_tune', 'tsm_forward_tap', 'tsm_last_forward_ms', 'tsm_set_layer_timing', 'tsm_layer_times', 'tsm_conv_tiles', 'tsm_temporal_shift', 'tsm_conv_bn_act',
            'tsm_maxpool3x3s2', 'tsm_head', 'tsm_preprocess', 'tsm_gather_clips', 'tsm_scores_to_states')
 
@@ -59,6 +59,12 @@ def load() -> C.CDLL:
     vp, fp, i32, i64 = C.c_void_p, C.c_void_p, C.c_int32, C.c_int64  # float* travel as raw addresses
     lib.tsm_abi_version.restype = C.c_int
     lib.tsm_abi_version.argtypes = []
+    lib.tsm_build_id.restype = C.c_char_p
+    lib.tsm_build_id.argtypes = []
+    lib.tsm_trace_launches.restype = C.c_int
+    lib.tsm_trace_launches.argtypes = [i32]
+    lib.tsm_launch_trace.restype = i64
+    lib.tsm_launch_trace.argtypes = [C.c_char_p, i64]
     lib.tsm_create.restype = C.c_int
     lib.tsm_create.argtypes = [C.POINTER(TsmConfig), C.POINTER(vp)]
     lib.tsm_destroy.restype = None
@@ -99,6 +105,12 @@ def load() -> C.CDLL:
     lib.tsm_scores_to_states.argtypes = [fp, i32, i32, i32, C.c_float, vp, fp, vp]
     if lib.tsm_abi_version() != ABI_VERSION:
         raise ImportError(f'libtsm_hip.so ABI {lib.tsm_abi_version()} != binding {ABI_VERSION}; rebuild')
+    # The library is git-ignored and travels prebuilt: refuse one that was not built from THIS tree (a stale .so would be
+    # tested and benchmarked silently).  TSM_LIB_PATH names an A/B build on purpose and is taken as it is.
+    have, want = lib.tsm_build_id().decode(), build_id()
+    if have != want and not os.environ.get('TSM_LIB_PATH'):
+        raise ImportError(f'{LIB_PATH} was built from other sources (build id {have}, this tree is {want}): '
+                          'rebuild it with `python -m workoutdetector_amd.build`')
     _lib = lib
     return lib
 

@@ -59,14 +59,48 @@ def csrc_sha16() -> str:
             h.update(' '.join(EXTRA_FLAGS.get(name, [])).encode())      # per-file compiler options change the code object too
             with open(os.path.join(CSRC, name), 'rb') as f:
                 h.update(f.read())
+    h.update(b'include/tsm_hip.h')
+    with open(os.path.join(INCLUDE, 'tsm_hip.h'), 'rb') as f:      # the ABI header is compiled into the engine object
+        h.update(f.read())
     return h.hexdigest()[:16]
 
 
+def build_defs() -> List[str]:
+    """Extra compiler definitions of an A/B build (TSM_BUILD_DEFS); empty for the product."""
+    return os.environ.get('TSM_BUILD_DEFS', '').split()
+
+
+def build_id() -> str:
+    """What the library built from THIS tree with THIS environment reports as tsm_build_id(): the sha of csrc/ (contents and
+    per-file options) and, for an A/B build, of its extra definitions -- two variant libraries of one source never share a
+    tune-cache line or pass for each other."""
+    defs = build_defs()
+    if not defs:
+        return csrc_sha16()
+    import hashlib
+    return hashlib.sha256((csrc_sha16() + ' ' + ' '.join(defs)).encode()).hexdigest()[:16]
+
+
+def library_build_id(path: str = None) -> str:
+    """The id compiled into an existing library file, read from the FILE (the engine object carries the string
+    'tsm-build-id:<id>'); '' when there is none.  Nothing is loaded or executed."""
+    try:
+        with open(path or LIB_PATH, 'rb') as f:
+            blob = f.read()
+    except OSError:
+        return ''
+    tag = b'tsm-build-id:'
+    i = blob.find(tag)
+    if i < 0:
+        return ''
+    j = blob.find(b'\0', i)
+    return blob[i + len(tag):j].decode('ascii', 'replace')
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    """A library is current when it carries the id of this tree (content, not mtimes: the git-ignored .so travels to the GPU
+    box by copy, and a copy does not keep the order of modification times)."""
+    return library_build_id() != build_id()
 
 
 def _headers() -> List[str]:
@@ -76,7 +110,7 @@ def _headers() -> List[str]:
 def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
-    defs = os.environ.get('TSM_BUILD_DEFS', '').split()
+    defs = build_defs()
     # A/B builds (TSM_LIB_PATH / TSM_BUILD_DEFS) keep their objects apart from the product's
     tag = '' if not (defs or os.environ.get('TSM_LIB_PATH')) else '_' + hashlib_tag(' '.join(defs) + LIB_PATH)
     obj_dir = OBJ_DIR + tag
@@ -90,7 +124,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header) \
             or src == 'tsm_engine.hip'
         if stale:
-            cmd = base + EXTRA_FLAGS.get(src, []) + ([f'-DTSM_BUILD_ID="{csrc_sha16()}"'] if src == 'tsm_engine.hip' else []) + \
+            cmd = base + EXTRA_FLAGS.get(src, []) + ([f'-DTSM_BUILD_ID="{build_id()}"'] if src == 'tsm_engine.hip' else []) + \
                 ['-c', path, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)

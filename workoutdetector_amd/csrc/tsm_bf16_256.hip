@@ -630,11 +630,11 @@ hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s) {
   constexpr size_t kLdsBytes = kLds256Bytes;
   const DeviceInfo &di = device_info();   // the > 64 KB dynamic-LDS opt-in, once per device
   if (di.status != hipSuccess) return di.status;
-  if (ks == 3) hipLaunchKernelGGL((conv_bf16_256_kernel<3, false>), grid, block, kLdsBytes, s, p);
-  else if (p.T > 0) hipLaunchKernelGGL((conv_bf16_256_kernel<1, true>), grid, block, kLdsBytes, s, p);
-  else if (p.res) hipLaunchKernelGGL((conv_bf16_256_kernel<1, false, true, false>), grid, block, kLdsBytes, s, p);
-  else if (p.x2) hipLaunchKernelGGL((conv_bf16_256_kernel<1, false, false, true>), grid, block, kLdsBytes, s, p);
-  else hipLaunchKernelGGL((conv_bf16_256_kernel<1, false>), grid, block, kLdsBytes, s, p);
+  if (ks == 3) TSM_KLAUNCH((conv_bf16_256_kernel<3, false>), grid, block, kLdsBytes, s, p);
+  else if (p.T > 0) TSM_KLAUNCH((conv_bf16_256_kernel<1, true>), grid, block, kLdsBytes, s, p);
+  else if (p.res) TSM_KLAUNCH((conv_bf16_256_kernel<1, false, true, false>), grid, block, kLdsBytes, s, p);
+  else if (p.x2) TSM_KLAUNCH((conv_bf16_256_kernel<1, false, false, true>), grid, block, kLdsBytes, s, p);
+  else TSM_KLAUNCH((conv_bf16_256_kernel<1, false>), grid, block, kLdsBytes, s, p);
   return hipGetLastError();
 }
 
@@ -647,11 +647,11 @@ hipError_t launch_conv_bf16_256p(ConvParams p, int ks, hipStream_t s) {
   const int ntiles = p.ntm * p.ntn;
   const int slots = di.n_cu & ~7;          // a multiple of 8: a workgroup's tiles then all sit in its own XCD's chunk
   const dim3 grid((unsigned)(ntiles < slots || slots < 8 ? ntiles : slots)), block(512);
-  if (ks == 3) hipLaunchKernelGGL((conv_bf16_256p_kernel<3, false>), grid, block, kLds256pBytes, s, p);
-  else if (p.T > 0) hipLaunchKernelGGL((conv_bf16_256p_kernel<1, true>), grid, block, kLds256pBytes, s, p);
-  else if (p.res) hipLaunchKernelGGL((conv_bf16_256p_kernel<1, false, true, false>), grid, block, kLds256pBytes, s, p);
-  else if (p.x2) hipLaunchKernelGGL((conv_bf16_256p_kernel<1, false, false, true>), grid, block, kLds256pBytes, s, p);
-  else hipLaunchKernelGGL((conv_bf16_256p_kernel<1, false>), grid, block, kLds256pBytes, s, p);
+  if (ks == 3) TSM_KLAUNCH((conv_bf16_256p_kernel<3, false>), grid, block, kLds256pBytes, s, p);
+  else if (p.T > 0) TSM_KLAUNCH((conv_bf16_256p_kernel<1, true>), grid, block, kLds256pBytes, s, p);
+  else if (p.res) TSM_KLAUNCH((conv_bf16_256p_kernel<1, false, true, false>), grid, block, kLds256pBytes, s, p);
+  else if (p.x2) TSM_KLAUNCH((conv_bf16_256p_kernel<1, false, false, true>), grid, block, kLds256pBytes, s, p);
+  else TSM_KLAUNCH((conv_bf16_256p_kernel<1, false>), grid, block, kLds256pBytes, s, p);
   return hipGetLastError();
 }
 

@@ -494,14 +494,14 @@ hipError_t launch_bneck_ws(const BneckParams &p, hipStream_t s) {
   if (di.status != hipSuccess) return di.status;
   const dim3 grid((unsigned)(p.N < di.n_cu ? p.N : di.n_cu)), block(256);
   if (p.cin == 256 && p.W == 64) {   // the identity from the input slots in LDS
-    if (p.T > 0) hipLaunchKernelGGL((bneck_ws_kernel<256, true, true>), grid, block, BnLds<256>::kBytesIdl, s, p);
-    else hipLaunchKernelGGL((bneck_ws_kernel<256, false, true>), grid, block, BnLds<256>::kBytesIdl, s, p);
+    if (p.T > 0) TSM_KLAUNCH((bneck_ws_kernel<256, true, true>), grid, block, BnLds<256>::kBytesIdl, s, p);
+    else TSM_KLAUNCH((bneck_ws_kernel<256, false, true>), grid, block, BnLds<256>::kBytesIdl, s, p);
   } else if (p.cin == 256) {
-    if (p.T > 0) hipLaunchKernelGGL((bneck_ws_kernel<256, true>), grid, block, BnLds<256>::kBytes, s, p);
-    else hipLaunchKernelGGL((bneck_ws_kernel<256, false>), grid, block, BnLds<256>::kBytes, s, p);
+    if (p.T > 0) TSM_KLAUNCH((bneck_ws_kernel<256, true>), grid, block, BnLds<256>::kBytes, s, p);
+    else TSM_KLAUNCH((bneck_ws_kernel<256, false>), grid, block, BnLds<256>::kBytes, s, p);
   } else {
-    if (p.T > 0) hipLaunchKernelGGL((bneck_ws_kernel<64, true>), grid, block, BnLds<64>::kBytes, s, p);
-    else hipLaunchKernelGGL((bneck_ws_kernel<64, false>), grid, block, BnLds<64>::kBytes, s, p);
+    if (p.T > 0) TSM_KLAUNCH((bneck_ws_kernel<64, true>), grid, block, BnLds<64>::kBytes, s, p);
+    else TSM_KLAUNCH((bneck_ws_kernel<64, false>), grid, block, BnLds<64>::kBytes, s, p);
   }
   return hipGetLastError();
 }

@@ -477,7 +477,7 @@ template <int K3, int C, int N1, int CH>
 static hipError_t launch_c31(const Conv31Params &p, long ntiles, int n_cu, hipStream_t s) {
   constexpr size_t kLdsBytes = C31<K3, C, N1, CH>::kBytes;
   const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(512);
-  hipLaunchKernelGGL((conv31_fused_kernel<K3, C, N1, CH>), grid, block, kLdsBytes, s, p);
+  TSM_KLAUNCH((conv31_fused_kernel<K3, C, N1, CH>), grid, block, kLdsBytes, s, p);
   return hipGetLastError();
 }
 

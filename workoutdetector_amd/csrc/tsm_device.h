@@ -112,6 +112,16 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
   }
 #undef TSM_VMCNT_CASE
 }
+// Every kernel launch of the library goes through this macro: the launch itself, plus one line in the calling thread's
+// launch trace when a test has switched it on (tsm_trace_launches; note_launch is a thread-local pointer test otherwise).
+// The trace names the kernel as the launch site spells it and, for a launch inside a template, the enclosing
+// function's template arguments -- so a parity test can assert that the kernel under test is the one that ran.
+#define TSM_KLAUNCH(kern, ...)                          \
+  do {                                                  \
+    ::tsm::note_launch(#kern, __PRETTY_FUNCTION__);     \
+    hipLaunchKernelGGL(kern, __VA_ARGS__);              \
+  } while (0)
+
 inline unsigned grid_for(int64_t total, int cap) {
   const int64_t blocks = (total + 255) / 256;
   return (unsigned)(blocks < cap ? (blocks > 0 ? blocks : 1) : cap);

@@ -33,6 +33,10 @@ namespace {
 
 using namespace tsm_host;
 
+// The tag is also what workoutdetector_amd/build.py looks for in the FILE to decide whether a prebuilt library belongs to
+// the tree it sits in (mtimes do not survive a copy to another machine).
+const char kBuildTag[] = "tsm-build-id:" TSM_BUILD_ID;
+
 constexpr int kBlocks[4] = {3, 4, 6, 3};
 constexpr int kPlanes[4] = {64, 128, 256, 512};
 
@@ -693,12 +697,15 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
 
 // The tile codes of the bucket `n_clips` falls into: already in memory, read from the tune cache file, or timed now on
 // the real launches over `d_clips` (synchronises; the codes then go to the cache file).
-int ensure_tuned(tsm_engine *e, const float *d_clips, int layout, int n_clips, float *d_out, hipStream_t s) {
+int ensure_tuned(tsm_engine *e, const float *d_clips, int layout, int n_clips, float *d_out, hipStream_t s,
+                 bool *from_file = nullptr) {
   const int tune_key = tile_bucket(n_clips) * e->cfg.num_segments;
+  if (from_file) *from_file = false;
   if (!e->autotune || e->tile_cache.find(tune_key) != e->tile_cache.end()) return TSM_OK;
   std::vector<int> cached(e->convs.size(), 0);
   if (tune_cache_load(e, tune_key, &cached)) {
     e->tile_cache.emplace(tune_key, cached);          // tuned by an earlier process (TSM_TUNE_CACHE)
+    if (from_file) *from_file = true;
     return TSM_OK;
   }
   std::vector<hipEvent_t> *saved = e->cur_timing;
@@ -742,6 +749,20 @@ int check_forward_args(tsm_engine *e, const void *clips, int memkind, int layout
 extern "C" {
 
 int tsm_abi_version(void) { return TSM_ABI_VERSION; }
+
+const char *tsm_build_id(void) { return kBuildTag + sizeof("tsm-build-id:") - 1; }
+
+int tsm_trace_launches(int32_t on) {
+  tsm::trace_launches(on != 0);
+  return TSM_OK;
+}
+
+int64_t tsm_launch_trace(char *buf, int64_t cap) {
+  const char *t = tsm::launch_trace();
+  const int64_t need = (int64_t)strlen(t) + 1;
+  if (buf && cap >= need) memcpy(buf, t, (size_t)need);
+  return need;
+}
 
 const char *tsm_last_error(const tsm_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
 
@@ -795,16 +816,6 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
       e->tune_path = default_tune_cache_path();
     }
   }
-  if (!e->tune_path.empty()) {
-    hipDeviceProp_t prop;
-    // (the build id: codes of another build of the library are still SAFE -- every code is validated against its layer at
-    //  launch -- but they were timed on other kernels, so they are not reused)
-    e->tune_sig = "abi" + std::to_string(TSM_ABI_VERSION) + " build " TSM_BUILD_ID " " +
-                  (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess ? std::string(prop.gcnArchName) : "?") +
-                  " T" + std::to_string(cfg->num_segments) + " " + std::to_string(cfg->height) + "x" +
-                  std::to_string(cfg->width) + " dtype" + std::to_string(cfg->dtype) + " shift" +
-                  std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0) + "/" + std::to_string(e->fuse23) + "/" + std::to_string(e->fuse_block) + "/" + std::to_string(e->fuse31);
-  }
   build_topology(e);
   st = hipSetDevice(cfg->device_id);
   if (st == hipSuccess) st = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -815,6 +826,20 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
     g_create_error = std::string("engine init: ") + hipGetErrorString(st);
     delete e;
     return TSM_ERR_HIP;
+  }
+  if (!e->tune_path.empty()) {
+    hipDeviceProp_t prop;
+    // (the build id -- csrc/, per-file options AND the build's extra definitions -- : codes of another build of the library
+    //  are still SAFE, every code is validated against its layer at launch, but they were timed on other kernels, so they
+    //  are not reused; the same goes for everything else that changes the timings: CU count, walk order, stem forms)
+    e->tune_sig = "abi" + std::to_string(TSM_ABI_VERSION) + " build " TSM_BUILD_ID " " +
+                  (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess ? std::string(prop.gcnArchName) : "?") +
+                  " cu" + std::to_string(e->n_cu) +
+                  " T" + std::to_string(cfg->num_segments) + " " + std::to_string(cfg->height) + "x" +
+                  std::to_string(cfg->width) + " dtype" + std::to_string(cfg->dtype) + " shift" +
+                  std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0) + "/" + std::to_string(e->fuse23) + "/" + std::to_string(e->fuse_block) + "/" + std::to_string(e->fuse31) +
+                  " zz" + std::to_string(e->zigzag ? 1 : 0) + " stem" + std::to_string(e->stem_direct ? 1 : 0) +
+                  std::to_string(e->stem_pool ? 1 : 0) + std::to_string(e->stem_planar ? 1 : 0);
   }
   *out = e;
   return TSM_OK;
@@ -1030,7 +1055,18 @@ int tsm_tune(tsm_engine *e, int32_t n_clips, void *stream) {
   const size_t frames = (size_t)n_clips * e->cfg.num_segments;
   TSM_HIP(e, hipMemsetAsync(e->d_in4, 0, frames * 4 * e->cfg.height * (e->cfg.width + 1) * sizeof(float), s));
   const int layout = e->prec == tsm::kPrecF32 ? TSM_LAYOUT_NTHWC4 : e->prec == tsm::kPrecBf16x3 ? TSM_LAYOUT_NTHWC8S : TSM_LAYOUT_NTHWC8B;
-  return ensure_tuned(e, e->d_in4, layout, n_clips, e->d_logits, s);
+  bool from_file = false;
+  int rc = ensure_tuned(e, e->d_in4, layout, n_clips, e->d_logits, s, &from_file);
+  if (rc || !from_file) return rc;
+  // The choices came from the cache file, so nothing has been launched yet: run the bucket's forward once on the zeroed
+  // buffer anyway.  Every kernel of the schedule is then loaded (the library bundles one code object per kernel family,
+  // each loaded lazily at its first launch) and the header's promise holds on this path too -- after tsm_tune a
+  // tsm_forward of the bucket allocates nothing, loads nothing and synchronises nothing.
+  std::vector<hipEvent_t> *saved = e->cur_timing;
+  e->cur_timing = nullptr;
+  rc = run_forward(e, e->d_in4, layout, n_clips, e->d_logits, s, nullptr, nullptr);
+  e->cur_timing = saved;
+  return rc;
 }
 
 int tsm_forward_tap(tsm_engine *e, const void *clips, int32_t memkind, int32_t layout, int32_t n_clips,

@@ -357,11 +357,11 @@ hipError_t launch_conv23_fused(const Fused23Params &p_in, int cmid, int prec, hi
   if (p.kseg_len < 0 || 6.0 * p.H * p.W * cmid * 4.0 > 2.0e9) return hipErrorInvalidValue;   // 32-bit offsets per window
   const unsigned grid = (unsigned)((p.M + 63) / 64);
   if (prec == kPrecBf16x3) {
-    if (cmid == 64) hipLaunchKernelGGL((conv23_fused_kernel<64, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv23_fused_kernel<128, true>), dim3(grid), dim3(512), 0, s, p);
+    if (cmid == 64) TSM_KLAUNCH((conv23_fused_kernel<64, true>), dim3(grid), dim3(256), 0, s, p);
+    else TSM_KLAUNCH((conv23_fused_kernel<128, true>), dim3(grid), dim3(512), 0, s, p);
   } else {
-    if (cmid == 64) hipLaunchKernelGGL((conv23_fused_kernel<64, false>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv23_fused_kernel<128, false>), dim3(grid), dim3(512), 0, s, p);
+    if (cmid == 64) TSM_KLAUNCH((conv23_fused_kernel<64, false>), dim3(grid), dim3(256), 0, s, p);
+    else TSM_KLAUNCH((conv23_fused_kernel<128, false>), dim3(grid), dim3(512), 0, s, p);
   }
   return hipGetLastError();
 }

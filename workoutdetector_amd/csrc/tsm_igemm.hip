@@ -701,11 +701,11 @@ static hipError_t launch_conv_seg(ConvParams p, hipStream_t s) {
     const dim3 block(64 * WGM * WGN);
     if constexpr (KS == 1 && !SHIFT) {
       if (p.x2) {
-        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecF32, true, true>), grid, block, 0, s, p);
+        TSM_KLAUNCH((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecF32, true, true>), grid, block, 0, s, p);
         return hipGetLastError();
       }
     }
-    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, false, kPrecF32, false, true>), grid, block, 0, s, p);
+    TSM_KLAUNCH((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, false, kPrecF32, false, true>), grid, block, 0, s, p);
     return hipGetLastError();
   }
 }
@@ -722,20 +722,20 @@ static hipError_t launch_conv_t(ConvParams p, hipStream_t s) {
   if constexpr (KS == 1 && !SHIFT && !RES) {
     if (p.x2) {
       if (p.prec == kPrecBf16x3)
-        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecBf16x3, true>), grid, dim3(64 * WGM * WGN), 0, s, p);
+        TSM_KLAUNCH((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecBf16x3, true>), grid, dim3(64 * WGM * WGN), 0, s, p);
       else if (p.prec == kPrecBf16)
-        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecBf16, true>), grid, dim3(64 * WGM * WGN), 0, s, p);
+        TSM_KLAUNCH((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecBf16, true>), grid, dim3(64 * WGM * WGN), 0, s, p);
       else
-        hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecF32, true>), grid, dim3(64 * WGM * WGN), 0, s, p);
+        TSM_KLAUNCH((conv_igemm<BM, BN, WGM, WGN, 1, false, false, kPrecF32, true>), grid, dim3(64 * WGM * WGN), 0, s, p);
       return hipGetLastError();
     }
   }
   if (p.prec == kPrecBf16x3)
-    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16x3>), grid, dim3(64 * WGM * WGN), 0, s, p);
+    TSM_KLAUNCH((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16x3>), grid, dim3(64 * WGM * WGN), 0, s, p);
   else if (p.prec == kPrecBf16)
-    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16>), grid, dim3(64 * WGM * WGN), 0, s, p);
+    TSM_KLAUNCH((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecBf16>), grid, dim3(64 * WGM * WGN), 0, s, p);
   else
-    hipLaunchKernelGGL((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32>), grid, dim3(64 * WGM * WGN), 0, s, p);
+    TSM_KLAUNCH((conv_igemm<BM, BN, WGM, WGN, KS, SHIFT, RES, kPrecF32>), grid, dim3(64 * WGM * WGN), 0, s, p);
   return hipGetLastError();
 }
 
@@ -882,7 +882,7 @@ hipError_t launch_splitk_reduce(const float *partial, int n_seg, int64_t m, int 
                                 const float *res, float *y, int relu, hipStream_t s) {
   if (!partial || !bias || !y || n_seg < 1 || m <= 0 || cout <= 0 || cout % 4 != 0) return hipErrorInvalidValue;
   const int64_t n4 = m * cout / 4;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n4, 2048)), dim3(256), 0, s, partial, n_seg, n4, n4, cout / 4,
+  TSM_KLAUNCH(splitk_reduce_kernel, dim3(grid_for(n4, 2048)), dim3(256), 0, s, partial, n_seg, n4, n4, cout / 4,
                      bias, res, y, relu);
   return hipGetLastError();
 }

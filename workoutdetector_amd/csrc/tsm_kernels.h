@@ -194,4 +194,9 @@ hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, 
 hipError_t launch_scores_to_states(const float *logits, int n, int c, int softmax, float threshold, int *states, float *top,
                                    hipStream_t s);
 
+// Launch trace of the calling thread (tsm_trace_launches / tsm_launch_trace in include/tsm_hip.h; tsm_ops.hip).
+void note_launch(const char *kernel, const char *where);
+void trace_launches(bool on);
+const char *launch_trace();   // newline-separated, valid until the thread's next trace call
+
 }  // namespace tsm

@@ -1,6 +1,8 @@
 // Small streaming kernels around the conv stack, and device_info().
 #include "tsm_device.h"
 
+#include <string>
+
 namespace tsm {
 
 // =============================================================================================
@@ -63,11 +65,11 @@ __device__ __forceinline__ void store_group(float *p, const float v[8]) {
 #define TSM_DISPATCH_FMT(prec, KERNEL, grid, stream, ...)                                                   \
   do {                                                                                                      \
     if ((prec) == kPrecBf16x3)                                                                              \
-      hipLaunchKernelGGL((KERNEL<kPrecBf16x3>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);             \
+      TSM_KLAUNCH((KERNEL<kPrecBf16x3>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);             \
     else if ((prec) == kPrecBf16)                                                                           \
-      hipLaunchKernelGGL((KERNEL<kPrecBf16>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);               \
+      TSM_KLAUNCH((KERNEL<kPrecBf16>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);               \
     else                                                                                                    \
-      hipLaunchKernelGGL((KERNEL<kPrecF32>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                \
+      TSM_KLAUNCH((KERNEL<kPrecF32>), dim3(grid), dim3(256), 0, stream, __VA_ARGS__);                \
   } while (0)
 
 // ---------------------------------------------------------------------------------------------
@@ -143,18 +145,18 @@ __global__ void __launch_bounds__(256) to_f32_kernel(const float *__restrict__ x
 }
 hipError_t launch_from_f32(const float *x, float *y, int64_t n8, int prec, hipStream_t s) {
   if (prec == kPrecBf16x3)
-    hipLaunchKernelGGL(from_f32_kernel<kPrecBf16x3>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
+    TSM_KLAUNCH(from_f32_kernel<kPrecBf16x3>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
   else if (prec == kPrecBf16)
-    hipLaunchKernelGGL(from_f32_kernel<kPrecBf16>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
+    TSM_KLAUNCH(from_f32_kernel<kPrecBf16>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
 }
 hipError_t launch_to_f32(const float *x, float *y, int64_t n8, int prec, hipStream_t s) {
   if (prec == kPrecBf16x3)
-    hipLaunchKernelGGL(to_f32_kernel<kPrecBf16x3>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
+    TSM_KLAUNCH(to_f32_kernel<kPrecBf16x3>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
   else if (prec == kPrecBf16)
-    hipLaunchKernelGGL(to_f32_kernel<kPrecBf16>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
+    TSM_KLAUNCH(to_f32_kernel<kPrecBf16>, dim3(grid_for(n8, 8192)), dim3(256), 0, s, x, y, n8);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
@@ -227,9 +229,9 @@ hipError_t launch_preprocess(const PreprocParams &p, hipStream_t s) {
   const int64_t total = (int64_t)p.n * p.crop * ((p.crop + px - 1) / px);
   const unsigned grid = grid_for(total, 8192);
   if (p.src_is_u8)
-    hipLaunchKernelGGL(preprocess_kernel<unsigned char>, dim3(grid), dim3(256), 0, s, p);
+    TSM_KLAUNCH(preprocess_kernel<unsigned char>, dim3(grid), dim3(256), 0, s, p);
   else
-    hipLaunchKernelGGL(preprocess_kernel<float>, dim3(grid), dim3(256), 0, s, p);
+    TSM_KLAUNCH(preprocess_kernel<float>, dim3(grid), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
@@ -287,7 +289,7 @@ hipError_t launch_gather_clips(const GatherParams &p_in, hipStream_t s) {
   for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
     p.row0 = r0;
     const int64_t ny = rows - r0 < 65535 ? rows - r0 : 65535;
-    hipLaunchKernelGGL(gather_clips_kernel, dim3(gx, (unsigned)ny), dim3(256), 0, s, p);
+    TSM_KLAUNCH(gather_clips_kernel, dim3(gx, (unsigned)ny), dim3(256), 0, s, p);
     const hipError_t st = hipGetLastError();
     if (st != hipSuccess) return st;
   }
@@ -368,7 +370,7 @@ hipError_t launch_temporal_shift(const float *x, float *y, int64_t n_frames, int
                                  int c, int fold, hipStream_t s) {
   if (c % 4 != 0 || fold % 4 != 0 || n_segment <= 0 || n_frames % n_segment != 0) return hipErrorInvalidValue;
   const int64_t total = n_frames * hw * (c / 4);
-  hipLaunchKernelGGL(temporal_shift_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, x, y, n_frames,
+  TSM_KLAUNCH(temporal_shift_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, x, y, n_frames,
                      n_segment, hw, c / 4, fold / 4);
   return hipGetLastError();
 }
@@ -434,14 +436,14 @@ hipError_t launch_head(const float *feat, const float *fc_w, const float *fc_b, 
   const int cg = c / (prec == kPrecF32 ? 4 : 8);
   const dim3 grid(n_clips * n_segment, (cg + 255) / 256);
   if (prec == kPrecBf16x3)
-    hipLaunchKernelGGL(head_pool_kernel<kPrecBf16x3>, grid, dim3(256), 0, s, feat, pooled, hw, c);
+    TSM_KLAUNCH(head_pool_kernel<kPrecBf16x3>, grid, dim3(256), 0, s, feat, pooled, hw, c);
   else if (prec == kPrecBf16)
-    hipLaunchKernelGGL(head_pool_kernel<kPrecBf16>, grid, dim3(256), 0, s, feat, pooled, hw, c);
+    TSM_KLAUNCH(head_pool_kernel<kPrecBf16>, grid, dim3(256), 0, s, feat, pooled, hw, c);
   else
-    hipLaunchKernelGGL(head_pool_kernel<kPrecF32>, grid, dim3(256), 0, s, feat, pooled, hw, c);
+    TSM_KLAUNCH(head_pool_kernel<kPrecF32>, grid, dim3(256), 0, s, feat, pooled, hw, c);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(head_fc_kernel, dim3(n_clips, num_class), dim3(64), 0, s, pooled, fc_w, fc_b, logits, c,
+  TSM_KLAUNCH(head_fc_kernel, dim3(n_clips, num_class), dim3(64), 0, s, pooled, fc_w, fc_b, logits, c,
                      num_class, n_segment);
   return hipGetLastError();
 }
@@ -502,10 +504,36 @@ __global__ void __launch_bounds__(64) scores_to_states_kernel(const float *__res
 hipError_t launch_scores_to_states(const float *logits, int n, int c, int softmax, float threshold, int *states, float *top,
                                    hipStream_t s) {
   if (!logits || !states || n <= 0 || c <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(scores_to_states_kernel, dim3((n + 63) / 64), dim3(64), 0, s, logits, n, c, softmax, threshold, states, top);
+  TSM_KLAUNCH(scores_to_states_kernel, dim3((n + 63) / 64), dim3(64), 0, s, logits, n, c, softmax, threshold, states, top);
   return hipGetLastError();
 }
 
+
+// ---- launch trace (tests): which kernels did this thread launch? ---------------------------------------------------
+namespace {
+struct LaunchTrace {
+  bool on = false;
+  std::string text;
+};
+thread_local LaunchTrace g_trace;
+}  // namespace
+
+void note_launch(const char *kernel, const char *where) {
+  if (!g_trace.on) return;
+  // "(conv_igemm<BM, BN, ...>)" as the launch site spells it; inside a template the enclosing function's
+  // "[BM = 64, BN = 64, ...]" (clang's __PRETTY_FUNCTION__) resolves the names
+  std::string k(kernel);
+  if (!k.empty() && k.front() == '(' && k.back() == ')') k = k.substr(1, k.size() - 2);
+  const char *with = where ? strstr(where, " [") : nullptr;
+  g_trace.text += k;
+  if (with) g_trace.text += with;
+  g_trace.text += '\n';
+}
+void trace_launches(bool on) {
+  g_trace.on = on;
+  if (on) g_trace.text.clear();
+}
+const char *launch_trace() { return g_trace.text.c_str(); }
 
 hipError_t lds_opt_in(const void *kernel, size_t bytes) {
   return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

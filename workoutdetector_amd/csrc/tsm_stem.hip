@@ -577,14 +577,14 @@ hipError_t launch_stem_pool(const float *x, const float *w, const float *bias, f
   const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
 #define TSM_STEM_ARGS dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, hp, wp, kp, relu
   if (prec == kPrecF32) {
-    if (planar) hipLaunchKernelGGL(stem_pool_f32_kernel<true>, TSM_STEM_ARGS);
-    else hipLaunchKernelGGL(stem_pool_f32_kernel<false>, TSM_STEM_ARGS);
+    if (planar) TSM_KLAUNCH(stem_pool_f32_kernel<true>, TSM_STEM_ARGS);
+    else TSM_KLAUNCH(stem_pool_f32_kernel<false>, TSM_STEM_ARGS);
   } else if (prec == kPrecBf16) {
-    if (planar) hipLaunchKernelGGL((stem_pool_kernel<false, true>), TSM_STEM_ARGS);
-    else hipLaunchKernelGGL((stem_pool_kernel<false, false>), TSM_STEM_ARGS);
+    if (planar) TSM_KLAUNCH((stem_pool_kernel<false, true>), TSM_STEM_ARGS);
+    else TSM_KLAUNCH((stem_pool_kernel<false, false>), TSM_STEM_ARGS);
   } else {
-    if (planar) hipLaunchKernelGGL((stem_pool_kernel<true, true>), TSM_STEM_ARGS);
-    else hipLaunchKernelGGL((stem_pool_kernel<true, false>), TSM_STEM_ARGS);
+    if (planar) TSM_KLAUNCH((stem_pool_kernel<true, true>), TSM_STEM_ARGS);
+    else TSM_KLAUNCH((stem_pool_kernel<true, false>), TSM_STEM_ARGS);
   }
 #undef TSM_STEM_ARGS
   return hipGetLastError();
@@ -602,9 +602,9 @@ hipError_t launch_stem_direct(const float *x, const float *w, const float *bias,
   const long cap = (long)device_info().n_cu * (prec == kPrecBf16 ? 2 : 1);
   const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
   if (prec == kPrecBf16)
-    hipLaunchKernelGGL((stem_direct_kernel<false, 4>), dim3(grid), dim3(256), 0, s, x, w, bias, y, n, hi, wi, ho, wo, kp, relu);
+    TSM_KLAUNCH((stem_direct_kernel<false, 4>), dim3(grid), dim3(256), 0, s, x, w, bias, y, n, hi, wi, ho, wo, kp, relu);
   else
-    hipLaunchKernelGGL((stem_direct_kernel<true, 8>), dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, kp, relu);
+    TSM_KLAUNCH((stem_direct_kernel<true, 8>), dim3(grid), dim3(512), 0, s, x, w, bias, y, n, hi, wi, ho, wo, kp, relu);
   return hipGetLastError();
 }
 

@@ -503,7 +503,7 @@ static bool ws_s2_tile_geometry(int Ho, int Wo, int *tr_out, int *tc_out) {
     if (tr < 1) continue;
     const int patch = (2 * tr + 1) * (2 * tc + 1);
     if (patch > kS2PatchMax) continue;
-    if (2 * tr * (2 * tc + 1) + ws_s2_lanes_per_row(tc) + tc > kS2PatchMax) continue;   // idle lanes of a row read behind it: inside the plane
+    if (2 * tr * (2 * tc + 1) + ws_s2_lanes_per_row(tc) + tc >= kS2PatchMax) continue;   // idle lanes of a row read behind it: the largest position they form stays <= kS2PatchMax - 1, inside the plane
     const long tiles = (long)((Ho + tr - 1) / tr) * ((Wo + tc - 1) / tc);
     if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && patch < best_patch)) {
       best_tiles = tiles; best_tr = tr; best_tc = tc; best_patch = patch;
@@ -1071,7 +1071,7 @@ hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
     const long ntiles = (long)q.N * ((p.Ho + q.tr - 1) / q.tr) * ((p.Wo + q.tc - 1) / q.tc);
     const int n_cu = ws_grid_setup();
     if (device_info().status != hipSuccess) return device_info().status;
-    hipLaunchKernelGGL(conv3x3_ws128_kernel<true>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kS2LdsBytes, s, q);
+    TSM_KLAUNCH(conv3x3_ws128_kernel<true>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kS2LdsBytes, s, q);
     return hipGetLastError();
   }
   if (conv3x3_ws128_valid(p)) {
@@ -1082,7 +1082,7 @@ hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
     const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
     const int n_cu = ws_grid_setup();
     if (device_info().status != hipSuccess) return device_info().status;
-    hipLaunchKernelGGL(conv3x3_ws128_kernel<false>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kW8LdsBytes, s, q);
+    TSM_KLAUNCH(conv3x3_ws128_kernel<false>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kW8LdsBytes, s, q);
     return hipGetLastError();
   }
   if (!conv3x3_ws_valid(p)) return hipErrorInvalidValue;
@@ -1093,7 +1093,7 @@ hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
   const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
   const int n_cu = ws_grid_setup();
   if (device_info().status != hipSuccess) return device_info().status;
-  hipLaunchKernelGGL(conv3x3_ws_kernel<false>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kWsLdsBytes, s, q);
+  TSM_KLAUNCH(conv3x3_ws_kernel<false>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kWsLdsBytes, s, q);
   return hipGetLastError();
 }
 
@@ -1106,8 +1106,8 @@ hipError_t launch_conv1x1_ws(const ConvParams &p, hipStream_t s) {
   if (device_info().status != hipSuccess) return device_info().status;
   const int ntiles = (p.M + 127) / 128;
   const unsigned grid = (unsigned)(ntiles < n_cu ? ntiles : n_cu);
-  if (p.C == 256) hipLaunchKernelGGL(conv1x1_ws_kernel<256>, dim3(grid), dim3(256), 2 * 16 * 4096 + 256, s, q);
-  else hipLaunchKernelGGL(conv1x1_ws_kernel<64>, dim3(grid), dim3(256), 2 * 4 * 4096 + 256, s, q);
+  if (p.C == 256) TSM_KLAUNCH(conv1x1_ws_kernel<256>, dim3(grid), dim3(256), 2 * 16 * 4096 + 256, s, q);
+  else TSM_KLAUNCH(conv1x1_ws_kernel<64>, dim3(grid), dim3(256), 2 * 4 * 4096 + 256, s, q);
   return hipGetLastError();
 }
 
@@ -1123,10 +1123,10 @@ hipError_t launch_conv1x1_wsn(const ConvParams &p, hipStream_t s) {
   const int ntiles = (p.M + px - 1) / px;
   const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(256);
   constexpr size_t kLds = 2 * 65536 + 1024;
-  if (p.x2) hipLaunchKernelGGL((conv1x1_wsn_kernel<128, 256, true>), grid, block, kLds, s, q);
-  else if (p.C == 256) hipLaunchKernelGGL((conv1x1_wsn_kernel<256, 128, false>), grid, block, kLds, s, q);
-  else if (p.Cout == 128) hipLaunchKernelGGL((conv1x1_wsn_kernel<512, 128, false>), grid, block, kLds, s, q);
-  else hipLaunchKernelGGL((conv1x1_wsn_kernel<512, 256, false>), grid, block, kLds, s, q);
+  if (p.x2) TSM_KLAUNCH((conv1x1_wsn_kernel<128, 256, true>), grid, block, kLds, s, q);
+  else if (p.C == 256) TSM_KLAUNCH((conv1x1_wsn_kernel<256, 128, false>), grid, block, kLds, s, q);
+  else if (p.Cout == 128) TSM_KLAUNCH((conv1x1_wsn_kernel<512, 128, false>), grid, block, kLds, s, q);
+  else TSM_KLAUNCH((conv1x1_wsn_kernel<512, 256, false>), grid, block, kLds, s, q);
   return hipGetLastError();
 }
 
@@ -1145,7 +1145,7 @@ hipError_t launch_conv23_ws(const Fused23Params &p, hipStream_t s) {
   const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
   const int n_cu = ws_grid_setup();
   if (device_info().status != hipSuccess) return device_info().status;
-  hipLaunchKernelGGL(conv3x3_ws_kernel<true>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kWsLdsBytes3All, s, q);
+  TSM_KLAUNCH(conv3x3_ws_kernel<true>, dim3((unsigned)(ntiles < n_cu ? ntiles : n_cu)), dim3(256), kWsLdsBytes3All, s, q);
   return hipGetLastError();
 }
 

@@ -323,6 +323,36 @@ def create_model(num_class: int = 2, num_segments: int = 8, base_model: str = 'r
                      dtype=dtype)
 
 
+# ---- launch trace (tests): which kernels did the calls inside the block launch? ----------------------------
+class launch_trace:
+    """``with launch_trace() as tr: ...`` records one line per kernel launch the library makes from THIS thread inside the
+    block (``tsm_trace_launches`` / ``tsm_launch_trace``); afterwards ``tr.kernels`` is the list of kernel names as the launch
+    sites spell them (template arguments of an enclosing launcher template resolved in a trailing ``[BM = 64, ...]``) and
+    ``tr.ran('bneck_ws_kernel')`` asks for a family by prefix.  The bitwise tests of forced kernel forms use it to assert
+    that the kernel under test is the one that ran -- a silent fall-back would make 'bit-identical' trivially true."""
+
+    def __init__(self):
+        self.kernels: List[str] = []
+
+    def __enter__(self) -> 'launch_trace':
+        _lib.load().tsm_trace_launches(1)
+        return self
+
+    def __exit__(self, *exc) -> None:
+        lib = _lib.load()
+        need = int(lib.tsm_launch_trace(None, 0))
+        buf = C.create_string_buffer(need)
+        lib.tsm_launch_trace(buf, need)
+        lib.tsm_trace_launches(0)
+        self.kernels = [ln for ln in buf.value.decode().split('\n') if ln]
+
+    def ran(self, prefix: str) -> bool:
+        return any(k.startswith(prefix) for k in self.kernels)
+
+    def count(self, prefix: str) -> int:
+        return sum(k.startswith(prefix) for k in self.kernels)
+
+
 # ---- per-op wrappers over the C ABI (device tensors), used by tests ----------------------------------
 def _ptr(t) -> Optional[int]:
     return None if t is None else t.data_ptr()

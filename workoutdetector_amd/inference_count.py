@@ -656,19 +656,38 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
     marker in the video table, so that the others raise too instead of blocking in an all-gather that never completes."""
     rank, world = tdist.world_info()
     dev = _engine_device(model)
-    counts = [estimated_clips(it, frame_counter) for it in items]
-    owner = tdist.plan_video_shards(counts, world)
+    plan_failure: Optional[BaseException] = None
+    counts: List[int] = []
+    owner: List[int] = []
+    try:
+        counts = [estimated_clips(it, frame_counter) for it in items]
+        owner = tdist.plan_video_shards(counts, world)
+    except Exception as exc:       # (a frame_counter that raises on ONE rank): the others are about to enter the checksum exchange
+        if not tdist.collective_enabled():
+            raise
+        plan_failure = exc
     if tdist.collective_enabled():
         import zlib
-        sig = torch.tensor([[zlib.crc32(repr((owner, counts)).encode()), len(items)]], dtype=torch.int64)
+        # [checksum of the plan, videos, status]: the status word carries a planning failure into the first exchange, so that
+        # no rank is left blocked in it (ADVICE r4)
+        sig = torch.tensor([[zlib.crc32(repr((owner, counts)).encode()), len(items), 0 if plan_failure is None else 1]],
+                           dtype=torch.int64)
         sigs = tdist.all_gather_logits(sig.to(dev) if dev is not None and tdist.on_rccl() else sig).cpu()
+        failed = [r for r in range(world) if int(sigs[r, 2]) != 0]
+        if failed:
+            if plan_failure is not None:
+                raise plan_failure
+            raise RuntimeError(f'rank(s) {failed} failed while planning the dataset job; nothing was run (rank {rank})')
         if not bool((sigs == sigs[0]).all()):
-            raise RuntimeError(f'shard plan differs between ranks (checksum, videos) = {sigs.tolist()}: every rank must '
+            raise RuntimeError(f'shard plan differs between ranks (checksum, videos) = {sigs[:, :2].tolist()}: every rank must '
                                f'see the same dataset and frame counts (rank {rank})')
     mine = [v for v in range(len(items)) if owner[v] == rank]
-    # (the stager's worker starts on the first video here, before the host-side setup below)
-    pieces = prefetch_pieces(model, ((v, (lambda p=items[v].video_path: reader(p))) for v in mine))
-    try:
+
+    def make_pieces():
+        # (the stager's worker starts on the first video here, before the warm-up below)
+        return prefetch_pieces(model, ((v, (lambda p=items[v].video_path: reader(p))) for v in mine))
+
+    def warm() -> None:
         if dev is not None and hasattr(model, 'warmup') and mine:
             # Cold-job costs out of the loop (VERDICT r3 #6): the kernels of the two batch sizes this rank will run -- full
             # batches and the ragged last one -- are tuned (tsm_tune: the engine's own zeroed buffer, no torch kernel) or
@@ -677,17 +696,15 @@ def _inference_dataset_global(model, items: list, out_dir: str, checkpoint: str,
             my_clips = sum(counts[v] for v in mine)
             tail = my_clips % batch_clips
             model.warmup(sorted({b for b in (min(batch_clips, my_clips), tail) if b > 0}))
-        return _run_global(model, items, mine, counts, pieces, out_dir, checkpoint, transform, batch_clips, dev, rank, world)
-    finally:
-        pieces.close()       # (a failure anywhere below must not leave the stager blocked on its full queue)
+
+    # (the stager's start and the warm-up run INSIDE _run_global's failure bracket: a tsm_tune HIP error or an OOM in either
+    #  still reaches the other ranks through the status row of the final exchange)
+    return _run_global(model, items, mine, counts, make_pieces, warm, out_dir, checkpoint, transform, batch_clips, dev, rank, world)
 
 
-def _run_global(model, items: list, mine: List[int], counts: List[int], pieces, out_dir: str, checkpoint: str, transform,
-                batch_clips: int, dev, rank: int, world: int) -> Dict[str, torch.Tensor]:
-    """The loop, the score files and the final exchange of ``_inference_dataset_global``."""
-    batcher = _ClipBatcher(model, batch_clips)
-    writer = _ScoreWriter(out_dir, checkpoint, sum(counts[v] for v in mine) + 8 * len(mine),
-                          getattr(model, 'num_class', None), pin=dev is not None)
+def _run_global(model, items: list, mine: List[int], counts: List[int], make_pieces, warm, out_dir: str, checkpoint: str,
+                transform, batch_clips: int, dev, rank: int, world: int) -> Dict[str, torch.Tensor]:
+    """The stager's start, the warm-up, the loop, the score files and the final exchange of ``_inference_dataset_global``."""
     # rows of MY videos: [video index, frames, clips, classes]; the last row is this rank's status word (0 = loop completed)
     meta = torch.full((len(items) + 1, 4), -1, dtype=torch.int64)
     slot_of = {v: i for i, v in enumerate(mine)}
@@ -705,7 +722,14 @@ def _run_global(model, items: list, mine: List[int], counts: List[int], pieces, 
 
     failure: Optional[BaseException] = None
     per_video: List[torch.Tensor] = []
+    pieces = None
+    batcher = writer = None
     try:
+        pieces = make_pieces()
+        warm()
+        batcher = _ClipBatcher(model, batch_clips)
+        writer = _ScoreWriter(out_dir, checkpoint, sum(counts[v] for v in mine) + 8 * len(mine),
+                              getattr(model, 'num_class', None), pin=dev is not None)
         for v, st, last in pieces:
             slot = slot_of[v]
             done = max(0, int(meta[slot, 2]))
@@ -720,10 +744,13 @@ def _run_global(model, items: list, mine: List[int], counts: List[int], pieces, 
         batcher.flush()
         hand_over(True)
         per_video = writer.drain()                                 # host rows of my videos, in ``mine`` order
-    except Exception as exc:                                       # (reader error, OOM, ...): still take part in the exchange below
+    except Exception as exc:                                       # (reader error, tuning error, OOM, ...): still take part in the exchange below
         if not tdist.collective_enabled():
             raise
         failure = exc
+    finally:
+        if pieces is not None:
+            pieces.close()       # (a failure anywhere above must not leave the stager blocked on its full queue)
     num_class = getattr(model, 'num_class', None) or (int(per_video[0].shape[1]) if per_video else 0)
     local = (torch.cat([t.reshape(-1, num_class) for t in per_video], dim=0) if per_video and failure is None
              else torch.empty((0, num_class), dtype=torch.float32))
