@@ -555,8 +555,8 @@ def test_conv3_conv1_cross_block_kernel_equals_the_separate_launches_bitwise(hip
         # T = 64; T = 32 on the 128-row forms) fall back; forced off, none runs.
         # (a tile is `rows` = T frames x rows / T >= 8 pixels: 256 rows on the 8-wave form, 128 on the wave-pair forms)
         for rows, inst in ((256, 'conv31_fused_kernel<K3, C, N1, CH> [K3 = 128, C = 512, N1 = 128, CH = 1]'),
-                           (128, 'conv31_fused_kernel<K3, C, N1, CH> [K3 = 128, C = 512, N1 = 256, CH = 2]'),
-                           (128, 'conv31_fused_kernel<K3, C, N1, CH> [K3 = 256, C = 1024, N1 = 256, CH = 2]')):
+                           (128, 'conv31_pc_kernel<K3, C, N1> [K3 = 128, C = 512, N1 = 256]'),       # (round 5: producer / consumer waves)
+                           (128, 'conv31_pc_kernel<K3, C, N1> [K3 = 256, C = 1024, N1 = 256]')):
             has_tile = flag == '1' and rows % t == 0 and rows // t >= 8
             assert tr.ran(inst) == has_tile, (flag, inst, sorted(set(tr.kernels)))
     for name, a, c in zip(('logits',) + stages + ('logits again',), got['1'], got['0']):
@@ -574,7 +574,7 @@ def test_tuner_may_choose_the_cross_block_kernel_and_reports_it(hip_lib, sd0):
     ya = eng.run(None, {'input': x})[0]
     with launch_trace() as tr:
         assert np.array_equal(eng.run(None, {'input': x})[0], ya)
-    n31 = tr.count('conv31_fused_kernel')
+    n31 = tr.count('conv31_fused_kernel') + tr.count('conv31_pc_kernel')
     tiles = eng.conv_tiles(4)
     eng.close()
     fused = [k for k, v in tiles.items() if v.endswith('+conv1')]

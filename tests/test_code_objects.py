@@ -175,3 +175,47 @@ def test_cross_block_kernel_budget_and_wait_tables(md):
         got = table(**cfg)
         assert got == simulate(**cfg), cfg
         assert max(max(v) for v in got.values()) < 64           # vmcnt is a 6-bit field
+
+
+def test_producer_consumer_cross_block_kernel_budget_and_waits(md):
+    """conv31_pc_kernel (round 5: the 128-row tiles with specialised waves): two waves per SIMD -> at most 256 registers, NO
+    scratch; 162 432 / 146 048 B of dynamic LDS = one workgroup per CU.  The producers' residual and t2 loads are issued from
+    inline asm (hipcc's own wait insertion must not see them: it cut round 4's two-chunk request stream to one), so their
+    counted waits are the ONLY thing between a load and its first use: C31P::wait_res restated here against a brute-force
+    simulation of the producers' issue order, for both instantiations and residual depths 2 and 4."""
+    for args, lds in (('128, 512, 256', 146048), ('256, 1024, 256', 162432)):
+        r = _one(md, f'conv31_pc_kernel<{args}>')
+        assert r['.max_flat_workgroup_size'] == 512 and r['.vgpr_count'] <= 256
+        assert r['.private_segment_fixed_size'] == 0 and r['.vgpr_spill_count'] == 0
+        assert lds <= codeobj.LDS_PER_CU and codeobj.workgroups_per_cu(r, lds) == 1
+
+    def simulate(NC, NQ, AF, RD):
+        ops = []
+        for t in range(4):
+            for c in range(NC):
+                if c == NC - 1:
+                    ops += [(t, c, 'AF', i) for i in range(AF)]          # the next tile's A fragments, behind barrier B
+                for q in range(NQ):
+                    ops += [(t, c, 'st', q), (t, c, 'ld', q)]            # store y, request the residual of chunk c + RD
+        at = {o: i for i, o in enumerate(ops)}
+        out = {}
+        for c in range(NC):
+            t0, c0 = divmod(2 * NC + c - RD, NC)
+            res = {at[(2, c, 'st', q)] - 1 - at[(t0, c0, 'ld', q)] for q in range(NQ)}   # younger than the awaited load, at its use
+            assert len(res) == 1
+            out[c] = res.pop()
+        # ... and the A fragments at the head of the next tile: the 2 NQ epilogue operations of the last chunk are younger
+        assert at[(2, 0, 'st', 0)] - 1 - at[(1, NC - 1, 'AF', AF - 1)] == 2 * NQ
+        return out
+
+    def table(NC, NQ, AF, RD):
+        return {nc: 2 * (NQ - 1) + 2 * NQ * (RD - 1) + sum(AF for k in range(1, RD + 1) if (nc - RD + k + NC) % NC == NC - 1)
+                for nc in range(NC)}
+
+    for cfg in (dict(NC=8, NQ=4, AF=8, RD=2), dict(NC=16, NQ=4, AF=16, RD=2), dict(NC=16, NQ=4, AF=16, RD=4), dict(NC=8, NQ=4, AF=8, RD=4)):
+        got = table(**cfg)
+        assert got == simulate(**cfg), cfg
+        assert max(got.values()) < 64                          # vmcnt is a 6-bit field
+        # the kernel's two cases: chunks whose window (nc - RD, nc] holds a tile's last chunk, and the rest
+        wrap = {nc for nc in range(cfg['NC']) if nc == cfg['NC'] - 1 or nc < cfg['RD'] - 1}
+        assert {got[nc] for nc in wrap} == {got[0]} and {got[nc] for nc in set(range(cfg['NC'])) - wrap} == {got[cfg['RD'] - 1]}

@@ -74,7 +74,7 @@ def match_schedule(convs):
                 continue
             rows.append((p + '.conv2', [p + '.conv2'], nxt))
             r3 = take([p + '.conv3'] + ([p + '.downsample'] if (b == 0 and not separate_down) else []))
-            if r3 is not None and 'conv31_fused' in r3['Kernel_Name'] and k + 1 < len(blocks):
+            if r3 is not None and 'conv31_' in r3['Kernel_Name'] and k + 1 < len(blocks):
                 # conv3 + residual of this block and shift + conv1 of the next one in ONE launch: priced with both
                 rows[-1] = (p + '.conv3+' + blocks[k + 1] + '.conv1', rows[-1][1] + [blocks[k + 1] + '.conv1'], r3)
                 have_t1 = True
@@ -106,7 +106,7 @@ def main(path, frames=256, size=224):
         tot += dur
         totf += fl
         kn = r['Kernel_Name'].split('<')[1].split('>')[0] if '<' in r['Kernel_Name'] else r['Kernel_Name'][:30]
-        if any(k in r['Kernel_Name'] for k in ('conv23_fused', 'conv_bf16_256', 'conv3x3_ws', 'conv1x1_ws', 'bneck_ws', 'conv31_fused', 'stem_')):
+        if any(k in r['Kernel_Name'] for k in ('conv23_fused', 'conv_bf16_256', 'conv3x3_ws', 'conv1x1_ws', 'bneck_ws', 'conv31_fused', 'conv31_pc', 'stem_')):
             kn = r['Kernel_Name'].split('tsm::')[1].split('(')[0]
         grid = int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))
         print(f"{nm:34s} {kn:44s} wgs={grid:6d} {dur:8.1f}us {fl / dur / 1e6:7.1f} TF/s  vgpr={r.get('VGPR_Count','?')}")
