@@ -241,15 +241,22 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
         const int m = 32 * mt + l31;
         const int dr = m >= W ? 1 : 0, c = m - dr * W, r = r0 + dr;
         const bool ok = m < W2 && (unsigned)r < (unsigned)H;
+        // Issued from inline asm (round 5): hipcc's wait insertion counts register loads but NOT the LDS-DMA operations queued
+        // between them, so behind every counted wait below it put a vmcnt(2) / vmcnt(3) of its own in front of the first use --
+        // on the hardware's counter that drains the next step's input DMA and all but three stores, once per M-tile, on every
+        // wave (the uses are shared code for the waves that take the identity from LDS).  The counted waits name the registers
+        // ("+v") in front of their first consumer; the ISA is audited for moves of them (tests/test_code_objects.py).
+        asm volatile("s_nop 4" ::: "memory");            // (the descriptor may be fresh from scalar moves: nothing inside asm is padded)
         if constexpr (DUAL) {
           const unsigned o = ok ? (unsigned)((r * W + c) * XROW + half * 16) : kInvalid;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) res[mt][g] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)o, g * 32, 0);
+          for (int g = 0; g < 4; ++g)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(res[mt][g]) : "v"(o), "s"(rsrcR), "n"(g * 32) : "memory");
         } else {
           const unsigned o = ok ? (unsigned)((r * W + c) * 512 + (2 * wave) * 64 + 2 * half * 16) : kInvalid;
 #pragma unroll
-          for (int k = 0; k < 4; ++k)      // (the constant part rides in the scalar offset: one address register per M-tile)
-            res[mt][k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, (int)o, (k >> 1) * 64 + (k & 1) * 16, 0);
+          for (int k = 0; k < 4; ++k)      // (the constant part rides in the instruction's offset: one address register per M-tile)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(res[mt][k]) : "v"(o), "s"(rsrcR), "n"((k >> 1) * 64 + (k & 1) * 16) : "memory");
         }
       };
       {
@@ -423,6 +430,8 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
           if constexpr (mt < 2) wait_vmcnt(NDMA + 12);
           else wait_vmcnt(12);
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(res[mt][k]));   // (no consumer of the identity is scheduled above the counted wait)
         if constexpr (DUAL) {   // the downsample branch: K continues over the block input's 64 channels
 #pragma unroll
           for (int g = 0; g < 4; ++g)
