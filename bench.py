@@ -445,6 +445,8 @@ def main():
         # work it really does (its block's conv3 on top of the 3x3) and never mixed into the plain-3x3 group.
         groups = {}
         for r in dom:
+            if '+conv2' in tiles.get(r['name'].replace('.conv2', '.conv1'), ''):
+                continue      # layer2.0's 3x3 rode in its conv1's launch (front_s2_kernel): no launch of its own, no time of its own
             kern, with_conv3 = kernel_of(tiles[r['name']], dtype, r['cout'], r['s'])
             gf = 2.0 * r['macs'] * frames / 1e9
             if with_conv3:

@@ -595,3 +595,44 @@ def test_tuner_may_choose_the_cross_block_kernel_and_reports_it(hip_lib, sd0):
     finally:
         del os.environ['TSM_FUSE_C3C1']
     assert np.array_equal(ya, yb)
+
+
+@pytest.mark.parametrize('h,w,b,t,shift', [
+    (256, 256, 2, 16, True),     # the config-5 geometry: 64 x 64 frames at layer2.0's input, 32 output rows of 32 pixels
+    (224, 224, 2, 8, True),      # the headline geometry: 56 x 56 (a row is 56 of the slot's 64 pixels, 28 output pixels per row)
+    (64, 96, 5, 4, True),        # 16 x 24 frames, T = 4: 20 frames over 20 workgroups
+    (32, 256, 3, 1, True),       # 8 x 64 frames, single-frame clips (the shifted channels read zeros)
+    (224, 224, 1, 8, False),     # no temporal shift
+    (128, 40, 3, 3, True),       # 32 x 10 frames: narrow rows, odd segment count
+    (256, 256, 9, 16, True),     # 144 frames: more than one frame per workgroup on a big chip (the row pipeline runs across frames)
+    (90, 70, 2, 8, True),        # 23 x 18: odd height -- the forced switch must fall back, same bits
+    (270, 480, 1, 8, True),      # 68 x 120: rows too wide for a slot -- falls back as well
+])
+def test_front_of_layer2_0_as_one_launch_equals_the_separate_launches_bitwise(hip_lib, monkeypatch, h, w, b, t, shift):
+    """front_s2_kernel (round 5: temporal shift + conv1 + bn1 + ReLU + the stride-2 conv2 + bn2 + ReLU of layer2.0 as ONE
+    launch -- conv1 row by row into a three-row line buffer in LDS, conv2 from it; the 128-channel tensor between them never
+    exists in memory; models/tsm.py:35-50,125-137 + torchvision Bottleneck.conv1 / conv2) against the two launches it replaces:
+    conv2's tap (= the kernel's output), the block output and the logits bit for bit, and the trace shows which of them ran."""
+    from workoutdetector_amd.engine import TsmEngine, launch_trace
+    from workoutdetector_amd.weights import make_state_dict
+    sd = make_state_dict(17, 12)
+    x = make_input(900 + h + t, b, t, h, w)
+    stages = ('layer1.2', 'layer2.0.conv2', 'layer2.0', 'layer2.1')
+    got = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('TSM_FUSE_FRONT', flag)
+        eng = TsmEngine(num_segments=t, height=h, width=w, is_shift=shift, max_clips=b, state_dict=sd, dtype='bf16')
+        got[flag] = [eng.run(None, {'input': x})[0]]
+        with launch_trace() as tr:
+            got[flag] += [eng.forward_tap(x, s) for s in stages] + [eng.run(None, {'input': x})[0]]
+        eng.close()
+        hp, wp = (((h - 1) // 2 + 1) - 1) // 2 + 1, (((w - 1) // 2 + 1) - 1) // 2 + 1      # layer1's frame = layer2.0's input
+        fits = flag == '1' and hp % 2 == 0 and wp <= 64
+        kern = 'front_s2_kernel<true>' if shift else 'front_s2_kernel<false>'
+        # (the taps 'layer2.0.conv2', 'layer2.0', 'layer2.1' and the forward run layer2.0's front once each)
+        assert tr.count(kern) == (4 if fits else 0) and tr.ran('front_s2_kernel') == fits, (flag, sorted(set(tr.kernels)))
+        # ... and the launches it replaces ran exactly when it did not: layer2.0's conv1 is the only 256 -> 128 1x1, its conv2 the only stride-2 128 -> 128 3x3
+        assert tr.ran('conv3x3_ws128_kernel<true>') == (not fits) or not tr.ran('conv3x3_ws128_kernel'), sorted(set(tr.kernels))
+    for name, a, c in zip(('logits',) + stages + ('logits again',), got['1'], got['0']):
+        assert np.array_equal(a, c), name
+    assert np.isfinite(got['1'][0]).all() and np.array_equal(got['1'][0], got['1'][-1])

@@ -58,6 +58,10 @@ def match_schedule(convs):
                 first = next(it, None)
                 if first is None:
                     break
+                if 'front_s2' in first['Kernel_Name']:      # shift + conv1 + the stride-2 conv2 in one launch
+                    rows.append((p + '.conv1+conv2', [p + '.conv1', p + '.conv2'], first))
+                    r3 = take([p + '.conv3'] + ([p + '.downsample'] if b == 0 else []))
+                    continue
                 if 'bneck_ws' in first['Kernel_Name']:      # the whole Bottleneck in one launch
                     rows.append((p + ' (block)', [p + '.conv1', p + '.conv2', p + '.conv3'] + ([p + '.downsample'] if b == 0 else []), first))
                     continue
@@ -90,7 +94,7 @@ def main(path, frames=256, size=224):
     # a split-K layer is two launches: the conv and its splitk_reduce, whose time is added to the conv's row
     convs = []
     for r in fw:
-        if 'conv' in r['Kernel_Name'] or 'stem_' in r['Kernel_Name'] or 'bneck_ws' in r['Kernel_Name']:   # stem_direct / stem_pool = conv1 (+ max-pool); bneck_ws = a whole block
+        if 'conv' in r['Kernel_Name'] or 'stem_' in r['Kernel_Name'] or 'bneck_ws' in r['Kernel_Name'] or 'front_s2' in r['Kernel_Name']:   # stem_direct / stem_pool = conv1 (+ max-pool); bneck_ws = a whole block
             convs.append(dict(r))
         elif 'splitk_reduce' in r['Kernel_Name'] and convs:
             convs[-1]['End_Timestamp'] = int(convs[-1]['End_Timestamp']) + int(r['End_Timestamp']) - int(r['Start_Timestamp'])
@@ -106,13 +110,13 @@ def main(path, frames=256, size=224):
         tot += dur
         totf += fl
         kn = r['Kernel_Name'].split('<')[1].split('>')[0] if '<' in r['Kernel_Name'] else r['Kernel_Name'][:30]
-        if any(k in r['Kernel_Name'] for k in ('conv23_fused', 'conv_bf16_256', 'conv3x3_ws', 'conv1x1_ws', 'bneck_ws', 'conv31_fused', 'conv31_pc', 'stem_')):
+        if any(k in r['Kernel_Name'] for k in ('conv23_fused', 'conv_bf16_256', 'conv3x3_ws', 'conv1x1_ws', 'bneck_ws', 'conv31_fused', 'conv31_pc', 'front_s2', 'stem_')):
             kn = r['Kernel_Name'].split('tsm::')[1].split('(')[0]
         grid = int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))
         print(f"{nm:34s} {kn:44s} wgs={grid:6d} {dur:8.1f}us {fl / dur / 1e6:7.1f} TF/s  vgpr={r.get('VGPR_Count','?')}")
     span = (int(fw[-1]['End_Timestamp']) - int(fw[0]['Start_Timestamp'])) / 1e3
     print(f'sum conv {tot:.1f} us = {totf / tot / 1e6:.1f} TF/s; forward span {span:.1f} us; '
-          f'other kernels {sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in fw if "conv" not in r["Kernel_Name"] and "stem_" not in r["Kernel_Name"] and "bneck_ws" not in r["Kernel_Name"] and "splitk_reduce" not in r["Kernel_Name"]):.1f} us')
+          f'other kernels {sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in fw if "conv" not in r["Kernel_Name"] and "stem_" not in r["Kernel_Name"] and "bneck_ws" not in r["Kernel_Name"] and "front_s2" not in r["Kernel_Name"] and "splitk_reduce" not in r["Kernel_Name"]):.1f} us')
 
 
 if __name__ == '__main__':

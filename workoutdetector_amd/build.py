@@ -21,7 +21,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), 'include')
 LIB_PATH = os.environ.get('TSM_LIB_PATH') or os.path.join(PKG_DIR, 'libtsm_hip.so')
 # One translation unit per kernel family (csrc/tsm_device.h lists them): objects are rebuilt only when their own source or
 # a header changed, in parallel, then linked.
-SOURCES = ['tsm_igemm.hip', 'tsm_bf16_256.hip', 'tsm_ws.hip', 'tsm_bneck.hip', 'tsm_conv31.hip', 'tsm_fused23.hip',
+SOURCES = ['tsm_igemm.hip', 'tsm_bf16_256.hip', 'tsm_ws.hip', 'tsm_bneck.hip', 'tsm_conv31.hip', 'tsm_front.hip', 'tsm_fused23.hip',
            'tsm_stem.hip', 'tsm_ops.hip', 'tsm_engine.hip']
 OBJ_DIR = os.path.join(CSRC, 'obj')
 # Per-file compiler options.  tsm_bneck.hip: MFMA results in architectural VGPRs (the "vgprcd" form).  Its kernels pin 208
@@ -30,7 +30,8 @@ OBJ_DIR = os.path.join(CSRC, 'obj')
 # bound by exactly those) just to hand accumulators to the epilogues; the option leaves the weights where they are pinned.
 # tsm_ws.hip: the same for the weight-stationary kernels (884 -> 16 v_accvgpr_read in the file; their epilogues run from
 # registers).
-EXTRA_FLAGS = {'tsm_bneck.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'tsm_ws.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
+EXTRA_FLAGS = {'tsm_bneck.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'], 'tsm_ws.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1'],
+               'tsm_front.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 ARCH = 'gfx950'
 
 

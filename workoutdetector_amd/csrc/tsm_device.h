@@ -6,6 +6,7 @@
 //   tsm_ws.hip         weight-stationary bf16 kernels: conv3x3_ws[128], conv1x1_ws[n]
 //   tsm_bneck.hip      bneck_ws_kernel: a whole layer1 Bottleneck per launch (bf16)
 //   tsm_conv31.hip     conv31_fused_kernel: conv3 + residual of block b and shift + conv1 of block b + 1 per launch (bf16)
+//   tsm_front.hip      front_s2_kernel: shift + conv1 + stride-2 conv2 of layer2.0 per launch (bf16)
 //   tsm_fused23.hip    conv23_fused_kernel: conv2 + conv3 + residual per launch (fp32 / split-bf16)
 //   tsm_stem.hip       stem_direct / stem_pool[_f32]: the 7x7 stem with the max-pool fused behind it
 //   tsm_ops.hip        pack / convert / preprocess / gather_clips / maxpool / shift / head / scores_to_states, device_info()
@@ -141,6 +142,7 @@ hipError_t opt_in_bf16_256();
 hipError_t opt_in_ws();
 hipError_t opt_in_bneck();
 hipError_t opt_in_conv31();
+hipError_t opt_in_front();
 
 // launch functions one family's dispatch calls in another family's file
 hipError_t launch_conv_bf16_256(ConvParams p, int ks, hipStream_t s);

@@ -125,6 +125,7 @@ struct tsm_engine {
   int fuse23 = -1;   // TSM_FUSE_CONV23: 0 never, 1 wherever a block is eligible, unset: the autotuner times both forms
   int fuse_block = -1;   // TSM_FUSE_BLOCK: the same for the whole-Bottleneck kernel (bf16, layer1.1 / layer1.2)
   int fuse31 = -1;       // TSM_FUSE_C3C1: the same for conv3 of block b + shift + conv1 of block b + 1 as one launch (bf16, layer2)
+  int fuse_front = -1;   // TSM_FUSE_FRONT: the same for shift + conv1 + the stride-2 conv2 of layer2.0 as one launch (bf16)
   int n_cu = 256;
   int timing_left = 0;
   bool timing_only3x3 = false;
@@ -368,7 +369,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
   // against THIS layer: anything else falls back to the heuristic shape, so a stale, foreign or hand-edited cache
   // line can only cost speed.
   auto code_ok = [&](const tsm::ConvParams &p, int code) {
-    return code > 0 && (code & ~0x1D0F) == 0 && tsm::conv_tile_valid(p, code & 15);   // (0x400 / 0x800 / 0x1000: conv2 + conv3 / the whole block / conv3 + the next block's conv1 run fused, below)
+    return code > 0 && (code & ~0x3D0F) == 0 && tsm::conv_tile_valid(p, code & 15);   // (0x400 / 0x800 / 0x1000 / 0x2000: conv2 + conv3 / the whole block / conv3 + the next block's conv1 / conv1 + the stride-2 conv2 run fused, below)
   };
   int flip = 0;   // alternates the tile walk direction of consecutive conv launches (ConvParams::reverse)
   auto conv = [&](int idx, tsm::ConvParams p, int ks, bool is3x3) -> int {
@@ -529,8 +530,31 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       if (want(name)) { tapped = true; return hit(y, nn, ho, wo, c3.cout); }
       return TSM_OK;
     }
+    // shift + conv1 + the stride-2 conv2 of layer2.0 as ONE launch (bf16: front_s2_kernel; t1 never exists in memory): bit 0x2000
+    // of conv1's tile code (set by the tuning pass below when it beat the two tuned launches), or forced / forbidden through
+    // TSM_FUSE_FRONT
+    tsm::FrontParams pfr{};
+    const bool can_front = prec == tsm::kPrecBf16 && blk.stride == 2 && c1.cin == 256 && c1.cout == 128 && c2.cin == 128 && c2.cout == 128 &&
+                           !have_t1 && e->fuse_front != 0 && tsm::front_s2_valid(nn, hh, ww, shiftT, p1.fold) &&
+                           !want(name + ".conv1");
+    if (can_front) {
+      pfr.x = x; pfr.w1 = c1.d_w; pfr.bias1 = c1.d_b; pfr.w2 = c2.d_w; pfr.bias2 = c2.d_b; pfr.y = t2;
+      pfr.N = nn; pfr.H = hh; pfr.W = ww; pfr.T = shiftT; pfr.fold = p1.fold;
+    }
+    bool did_front = false;
+    if (can_front && !tuning && (e->fuse_front == 1 || (tiles && ((*tiles)[blk.conv1] & 0x2000)))) {
+      pfr.reverse = e->zigzag ? (flip ^= 1) : 0;
+      TSM_LAUNCH_K(e, s, false, tsm::launch_front_s2(pfr, s));
+      flip ^= 1;                                    // (it stands for two launches: conv3 keeps the direction it would have had)
+      if (e->cur_timing) {                          // keep conv2's launch slot: reported as "not recorded"
+        e->cur_timing->push_back(nullptr);
+        e->cur_timing->push_back(nullptr);
+      }
+      did_front = true;
+    }
     const int r1 = e->zigzag ? (flip ^ 1) : 0;   // the walk direction conv() is about to give conv1 (kept for the tuner's A/B below)
-    if (have_t1) {               // the previous block's conv3 launch computed this conv1 as well: keep the launch slot
+    if (did_front) {
+    } else if (have_t1) {               // the previous block's conv3 launch computed this conv1 as well: keep the launch slot
       if (e->cur_timing) {
         e->cur_timing->push_back(nullptr);
         e->cur_timing->push_back(nullptr);
@@ -567,7 +591,7 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
         if (one_ms < pair_ms) (*tiles)[prev.conv3_idx] |= 0x1000;
       }
     }
-    if (want(name + ".conv1")) { tapped = true; return hit(t1, nn, hh, ww, c1.cout); }
+    if (!did_front && want(name + ".conv1")) { tapped = true; return hit(t1, nn, hh, ww, c1.cout); }
     tsm::ConvParams p2 = make_params(c2, t1, nullptr, t2, nn, hh, ww, true, 0, 1, prec);
     // conv2 + conv3 + residual in one kernel where the block is eligible: bit 0x400 of conv2's tile code (set by the
     // tuning pass when the fused launch beat the two separate ones), or forced / forbidden through TSM_FUSE_CONV23
@@ -589,8 +613,35 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
       if (want(name)) { tapped = true; return hit(y, nn, ho, wo, c3.cout); }
       return TSM_OK;
     }
-    int rc2 = conv(blk.conv2, p2, 3, true);
-    if (rc2) return rc2;
+    if (!did_front) {
+      int rc2 = conv(blk.conv2, p2, 3, true);
+      if (rc2) return rc2;
+      if (tuning && can_front && e->fuse_front < 0) {
+        // the one launch against the two tuned ones, same protocol as the other fused forms (both arms write the same bits to t2)
+        const int code1 = (*tiles)[blk.conv1], code2 = (*tiles)[blk.conv2];
+        tsm::ConvParams pa = p1, pc = p2;
+        pa.reverse = r1;
+        pc.reverse = e->zigzag ? (r1 ^ 1) : 0;
+        pfr.reverse = r1;
+        float pair_ms = 0.f, one_ms = 0.f, ms[4];
+        for (int arm = 0; arm < 2; ++arm) {
+          for (int rep = 0; rep < 4; ++rep) {
+            TSM_HIP(e, hipEventRecord(e->ev0, s));
+            if (arm == 0) {
+              TSM_HIP(e, launch_code(pa, 1, code1));
+              TSM_HIP(e, launch_code(pc, 3, code2));
+            } else {
+              TSM_HIP(e, tsm::launch_front_s2(pfr, s));
+            }
+            TSM_HIP(e, hipEventRecord(e->ev1, s));
+            TSM_HIP(e, hipEventSynchronize(e->ev1));
+            TSM_HIP(e, hipEventElapsedTime(&ms[rep], e->ev0, e->ev1));
+          }
+          (arm == 0 ? pair_ms : one_ms) = std::min(ms[1], std::min(ms[2], ms[3]));
+        }
+        if (one_ms < pair_ms) (*tiles)[blk.conv1] |= 0x2000;
+      }
+    }
     if (want(name + ".conv2")) { tapped = true; return hit(t2, nn, ho, wo, c2.cout); }
     tsm::ConvParams p3 = make_params(c3, t2, fused ? nullptr : identity, y, nn, ho, wo, true, 0, 1, prec);
     if (fused) {
@@ -805,6 +856,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (const char *f23 = getenv("TSM_FUSE_CONV23")) e->fuse23 = atoi(f23) != 0;
   if (const char *fb = getenv("TSM_FUSE_BLOCK")) e->fuse_block = atoi(fb) != 0;
   if (const char *f31 = getenv("TSM_FUSE_C3C1")) e->fuse31 = atoi(f31) != 0;
+  if (const char *ff = getenv("TSM_FUSE_FRONT")) e->fuse_front = atoi(ff) != 0;
   if (const char *zz = getenv("TSM_ZIGZAG")) e->zigzag = atoi(zz) != 0;
   // TSM_TUNE_CACHE=<file> names the tune cache; unset: a per-user default ($XDG_CACHE_HOME or $HOME/.cache, then
   // tsm_hip/tune_cache.txt), so that the second process on a machine pays no tuning pass; "", "0" or "off" disables it.
@@ -837,7 +889,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
                   " cu" + std::to_string(e->n_cu) +
                   " T" + std::to_string(cfg->num_segments) + " " + std::to_string(cfg->height) + "x" +
                   std::to_string(cfg->width) + " dtype" + std::to_string(cfg->dtype) + " shift" +
-                  std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0) + "/" + std::to_string(e->fuse23) + "/" + std::to_string(e->fuse_block) + "/" + std::to_string(e->fuse31) +
+                  std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0) + "/" + std::to_string(e->fuse23) + "/" + std::to_string(e->fuse_block) + "/" + std::to_string(e->fuse31) + "/" + std::to_string(e->fuse_front) +
                   " zz" + std::to_string(e->zigzag ? 1 : 0) + " stem" + std::to_string(e->stem_direct ? 1 : 0) +
                   std::to_string(e->stem_pool ? 1 : 0) + std::to_string(e->stem_planar ? 1 : 0);
   }

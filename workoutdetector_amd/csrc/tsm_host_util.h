@@ -148,7 +148,7 @@ inline void pack_w3_fragments_split(const float *w3p, int cmid, std::vector<floa
 }
 
 // One line of a TSM_TUNE_CACHE file: "<signature>|<bucket>|c0,c1,...".  Succeeds only when the line starts with
-// `want`, holds exactly codes->size() integers and each is a ConvTile below `num_tiles`, optionally | 0x100 (split-K) | 0x400 (block runs conv2 + conv3 fused) | 0x800 (the whole block runs as one launch) | 0x1000 (conv3 also runs the next block's conv1).
+// `want`, holds exactly codes->size() integers and each is a ConvTile below `num_tiles`, optionally | 0x100 (split-K) | 0x400 (block runs conv2 + conv3 fused) | 0x800 (the whole block runs as one launch) | 0x1000 (conv3 also runs the next block's conv1) | 0x2000 (conv1 also runs the block's stride-2 conv2).
 // Anything else (foreign keys, truncated lines, garbage, overlong numbers) leaves *codes untouched.
 inline bool parse_tune_line(const char *line, const std::string &want, int num_tiles, std::vector<int> *codes) {
   if (strncmp(line, want.c_str(), want.size()) != 0) return false;
@@ -158,7 +158,7 @@ inline bool parse_tune_line(const char *line, const std::string &want, int num_t
     char *end = nullptr;
     const long v = strtol(q, &end, 10);
     if (end == q) return false;
-    if (v < 0 || (v & ~0x1D0FL) != 0 || (int)(v & 15) >= num_tiles) return false;
+    if (v < 0 || (v & ~0x3D0FL) != 0 || (int)(v & 15) >= num_tiles) return false;
     got.push_back((int)v);
     if (*end == ',') q = end + 1;
     else if (*end == '\n' || *end == 0) q = end;

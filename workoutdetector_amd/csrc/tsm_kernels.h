@@ -109,6 +109,23 @@ struct BneckParams {
 bool bneck_ws_valid(int cin, int n, int h, int w, int T, int fold);
 hipError_t launch_bneck_ws(const BneckParams &p, hipStream_t s);
 
+// Temporal shift + conv1 (1x1, 256 -> 128) + bn1 + ReLU + conv2 (3x3, stride 2, pad 1, 128 -> 128) + bn2 + ReLU of layer2.0 as ONE
+// launch (bf16, front_s2_kernel, tsm_front.hip): the 128-channel tensor between the two convolutions never exists in memory.
+// Bit-identical to launch_conv(conv1 with shift) followed by launch_conv(conv2).
+struct FrontParams {
+  const void *x;       // [N, H, W, 256] bf16: the block input
+  const void *w1;      // [128][256] bf16, bn1 scale folded in
+  const float *bias1;  // [128]
+  const void *w2;      // [128][1152] bf16, K = (ky, kx, c), bn2 scale folded in
+  const float *bias2;  // [128]
+  void *y;             // [N, H / 2, (W - 1) / 2 + 1, 128] bf16: conv2's output
+  int N, H, W;
+  int T, fold;         // temporal shift over T segments (0 = none), fold = 32
+  int reverse;         // walk the frames from the last one to the first
+};
+bool front_s2_valid(int n, int h, int w, int T, int fold);
+hipError_t launch_front_s2(const FrontParams &p, hipStream_t s);
+
 // conv3 + bn3 + residual + ReLU of Bottleneck b AND temporal shift + conv1 + bn1 + ReLU of Bottleneck b + 1 as ONE launch
 // (bf16, conv31_fused_kernel, tsm_conv31.hip): the block output y is written once (block b + 1's identity) and never read
 // back for conv1 -- a tile is all T frames of a clip x 256 / T pixels, so the frames t +- 1 the shifted channels come from

@@ -550,7 +550,7 @@ const DeviceInfo &device_info() {
   DeviceInfo di;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) di.n_cu = prop.multiProcessorCount;
-  for (hipError_t st : {opt_in_bf16_256(), opt_in_ws(), opt_in_bneck(), opt_in_conv31()})
+  for (hipError_t st : {opt_in_bf16_256(), opt_in_ws(), opt_in_bneck(), opt_in_conv31(), opt_in_front()})
     if (st != hipSuccess && di.status == hipSuccess) di.status = st;
   return seen.emplace(dev, di).first->second;
 }

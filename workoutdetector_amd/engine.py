@@ -235,9 +235,10 @@ class TsmEngine:
         kernel (the conv3 entry of that block is then unused); '+block' on a block's conv1 = the whole Bottleneck runs as one
         launch (bf16 layer1.1 / layer1.2; the conv2 / conv3 entries are then unused); '+conv1' on a block's conv3 = that
         launch also runs the NEXT block's shift + conv1 (bf16 layer2: conv31_fused_kernel; the next block's conv1 entry is then
-        unused)."""
+        unused); '+conv2' on a block's conv1 = that launch also runs the block's stride-2 conv2 (bf16 layer2.0: front_s2_kernel; the
+        conv2 entry is then unused)."""
         return (cls.TILE_NAMES[code & 15] + ('/splitK' if code & 0x100 else '') + ('+conv3' if code & 0x400 else '') +
-                ('+block' if code & 0x800 else '') + ('+conv1' if code & 0x1000 else ''))
+                ('+block' if code & 0x800 else '') + ('+conv1' if code & 0x1000 else '') + ('+conv2' if code & 0x2000 else ''))
 
     def conv_tiles(self, n_clips: int) -> Dict[str, str]:
         """Tile shape the autotuner chose per conv launch for an ``n_clips`` forward."""
