@@ -158,30 +158,40 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) nxt[mt][k] = u32x4{0u, 0u, 0u, 0u};
 
-  // LDS-DMA of the input of step s of frame f into this wave's slot: always NDMA operations (dead ones fetch nothing)
-  auto issue_x = [&](int f, int s, bool live) {
+  // LDS-DMA of the input of step s of frame f into this wave's slot: always NDMA operations (dead ones fetch nothing), which can be
+  // issued one at a time (IDL form: behind conv2's MFMAs -- in a burst behind the conv1 barrier a piece costs ~100 cycles of issue)
+  struct XDma {
+    const char *base;      // one frame BEFORE f (only ever addressed there when frame t - 1 exists)
+    unsigned vC, vA, vB;   // the pixel's row in its own frame, in frame t + 1, in frame t - 1
+  };
+  auto prep_x = [&](int f, int s, bool live) -> XDma {
+    XDma d;
     const int tt = p.T > 0 ? f % p.T : 0;
-    // the descriptor starts one frame BEFORE f (only ever addressed there when frame t - 1 exists)
-    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.x) + ((long)f - 1) * xframe), 0, 3 * xframe, 0x00020000);
+    d.base = reinterpret_cast<const char *>(p.x) + ((long)f - 1) * xframe;
     const int pix = 2 * s * W + md;
     const bool okp = live && md < W2 && pix < H * W;
     // three source rows per pixel: its own frame, frame t + 1, frame t - 1; a k16 group's 32 bytes are the instruction's
     // immediate offset, so a step costs three address registers, not one per group
     const unsigned own = (unsigned)xframe + (unsigned)pix * (unsigned)XROW + (unsigned)hsel * 16u;
-    const unsigned vC = okp ? own : kInvalid;
-    const unsigned vA = (okp && tt < p.T - 1) ? own + (unsigned)xframe : kInvalid;
-    const unsigned vB = (okp && tt > 0) ? own - (unsigned)xframe : kInvalid;
+    d.vC = okp ? own : kInvalid;
+    d.vA = (okp && tt < p.T - 1) ? own + (unsigned)xframe : kInvalid;
+    d.vB = (okp && tt > 0) ? own - (unsigned)xframe : kInvalid;
+    return d;
+  };
+  auto x_piece = [&](const XDma &d, auto gc) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(d.base), 0, 3 * xframe, 0x00020000);
     // fold = CIN / 8 channels: CIN 256 -- k16 groups 0, 1 from t + 1 and 2, 3 from t - 1; CIN 64 -- ONE 16-byte chunk each:
     // the two halves of k16 group 0 (the loader lane's hsel picks the chunk)
-    const unsigned v0 = !SHIFT ? vC : (DUAL ? (hsel ? vB : vA) : vA);
-    static_for<NG1>([&](auto gc) __attribute__((always_inline)) {
-      constexpr int g = decltype(gc)::value;
-      const unsigned v = !SHIFT ? vC : (DUAL ? (g == 0 ? v0 : vC) : (g < 2 ? vA : (g < 4 ? vB : vC)));
-      // (the instruction's immediate offset is added to the LDS address as well as to the memory address: the LDS base
-      //  carries g * 1024 - g * 32 so that plane g still starts at g * 1024)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(xs + g * (1024 - 32)), 16, (int)v, 0, g * 32, 0);
-    });
+    const unsigned v0 = !SHIFT ? d.vC : (DUAL ? (hsel ? d.vB : d.vA) : d.vA);
+    const unsigned v = !SHIFT ? d.vC : (DUAL ? (g == 0 ? v0 : d.vC) : (g < 2 ? d.vA : (g < 4 ? d.vB : d.vC)));
+    // (the instruction's immediate offset is added to the LDS address as well as to the memory address: the LDS base
+    //  carries g * 1024 - g * 32 so that plane g still starts at g * 1024)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(xs + g * (1024 - 32)), 16, (int)v, 0, g * 32, 0);
+  };
+  auto issue_x = [&](int f, int s, bool live) {
+    const XDma d = prep_x(f, s, live);
+    static_for<NG1>([&](auto gc) __attribute__((always_inline)) { x_piece(d, gc); });
   };
 
   // virtual frame index -> frame: XCD-chunked (the shifted quarter of conv1's input comes from frames f - 1 and f + 1: with
@@ -330,10 +340,10 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();    // rows 2s - 2 .. 2s + 1 are complete; nobody still reads the mid tile of the previous step
-      if constexpr (IDL) {             // ... nor anybody's input slot: re-arm it (a step minus the conv1 phase ahead)
-        if (s + 1 < nsteps) issue_x(f, s + 1, true);
-        else issue_x(fnext < 0 ? f : fnext, 0, fnext >= 0);
-      }
+      // IDL: ... nor anybody's input slot: re-arm it (a step minus the conv1 phase ahead), piece by piece behind conv2's MFMAs
+      // (round 5; behind the late identity loads in the wave's issue order)
+      XDma xd{};
+      if constexpr (IDL) xd = (s + 1 < nsteps) ? prep_x(f, s + 1, true) : prep_x(fnext < 0 ? f : fnext, 0, fnext >= 0);
       // ================= conv2: output rows r0, r0 + 1, M-tiles 2 hh, 2 hh + 1, mid channels 32 nt2 .. + 32 =================
       issue_res(2);
       issue_res(3);
@@ -369,9 +379,13 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
           constexpr int st = decltype(sc)::value;
           if constexpr (st + 3 < 36) rd(st + 3);
 #pragma unroll
-          for (int m = 0; m < 2; ++m)
+          for (int m = 0; m < 2; ++m) {
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w2r[st]), __builtin_bit_cast(bf16x8, px[st & 3][m]),
                                                              acc[m], 0, 0, 0);
+            if constexpr (IDL && st >= 2 && st < 2 + 2 * NDMA && (st & 1) == 0) {
+              if (m == 0) x_piece(xd, std::integral_constant<int, (st - 2) / 2>{});      // one piece every second step, behind an MFMA
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
         });
         // bias2, ReLU, bf16 -> the mid tile, in conv3's B-fragment order (plane g' = 2 nt2 + qq)
@@ -426,8 +440,10 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
         // (NDMA), the late loads (8), the stores so far (0 / 4) = NDMA + 12; M-tiles 2, 3 -- the other late loads and the
         // stores so far = 12
         // (IDL waves issue no late loads: [8 early loads | NDMA | 16 stores], and M-tiles 2, 3 wait for nothing)
+        // (IDL form, round 5: the input DMA rides on conv2's MFMAs, BEHIND the late loads in the issue order
+        //  [8 early loads | 8 late loads | NDMA | 16 stores]: NDMA + 12 for every M-tile)
         if (!idl) {
-          if constexpr (mt < 2) wait_vmcnt(NDMA + 12);
+          if constexpr (mt < 2 || IDL) wait_vmcnt(NDMA + 12);
           else wait_vmcnt(12);
         }
 #pragma unroll

@@ -632,24 +632,41 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
     const int hsel = (lane & 1) ^ ws128_swap(p.swz, pidx, PW);
     dslot[i] = (unsigned)((pr * W + pc) * 16 + hsel) | ((unsigned)pc << 24);
   }
-  auto issue_patch = [&](int t, int b) {
+  // The patch of a tile, as 2 x kRounds LDS-DMA operations that can be issued one at a time: in a burst behind the barrier a
+  // piece costs ~100 cycles of issue (in-kernel stamps of front_s2_kernel, round 5) -- 12 / 20 of them per tile against 144 / 72
+  // MFMAs of 32 cycles --, behind an MFMA about nothing.  Operation k = round k >> 1 of plane 2 wave + (k & 1).
+  struct PatchDma {
+    const char *base;      // the tile's frame
+    int tbase, x0;
+    unsigned char *dst;
+    bool live;
+  };
+  auto prep_patch = [&](int t, int b, bool live) -> PatchDma {
+    PatchDma d;
     const int f = t / tiles_f, rem = t - f * tiles_f;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-    const int x0 = S2 ? 2 * tx * TC - 1 : tx * TC - 1, y0 = S2 ? 2 * ty * TR - 1 : ty * TR - 1;   // the patch origin
-    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.x) + (size_t)f * frame_bytes), 0, frame_bytes, 0x00020000);
-    const int tbase = (y0 * W + x0) * 256 + 4 * wave * 16;
-    unsigned char *dst = lds + b * kBuf + 2 * wave * kPlane;
+    const int y0 = S2 ? 2 * ty * TR - 1 : ty * TR - 1;                  // the patch origin
+    d.x0 = S2 ? 2 * tx * TC - 1 : tx * TC - 1;
+    d.base = reinterpret_cast<const char *>(p.x) + (size_t)f * frame_bytes;
+    d.tbase = (y0 * W + d.x0) * 256 + 4 * wave * 16;
+    d.dst = lds + b * kBuf + 2 * wave * kPlane;
+    d.live = live;
+    return d;
+  };
+  auto patch_piece = [&](const PatchDma &d, int k) {
+    const int i = k >> 1, pl = k & 1;
+    if (d.live && i < nr && (!S2 || i < kS2Rounds - 1 || lane < 2)) {   // (S2's tenth round: position 288 alone)
+      const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(d.base), 0, frame_bytes, 0x00020000);
+      const int xg = d.x0 + (int)(dslot[i] >> 24);
+      const unsigned off = (unsigned)d.tbase + ((dslot[i] & 0xFFFFFFu) << 4) + (pl ? 32u : 0u);
+      const unsigned o = (unsigned)xg < (unsigned)W ? off : kInvalid;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(d.dst + pl * kPlane + i * 1024), 16, (int)o, 0, 0, 0);
+    }
+  };
+  auto issue_patch = [&](int t, int b) {
+    const PatchDma d = prep_patch(t, b, true);
 #pragma unroll
-    for (int i = 0; i < kRounds; ++i)
-      if (i < nr && (!S2 || i < kS2Rounds - 1 || lane < 2)) {       // (S2's tenth round: position 288 alone)
-        const int xg = x0 + (int)(dslot[i] >> 24);
-        const unsigned off = (unsigned)tbase + ((dslot[i] & 0xFFFFFFu) << 4);
-        const unsigned o = (unsigned)xg < (unsigned)W ? off : kInvalid;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(dst + i * 1024), 16, (int)o, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void *)(dst + kPlane + i * 1024), 16,
-                                                 (int)(o == kInvalid ? kInvalid : o + 32u), 0, 0, 0);
-      }
+    for (int k = 0; k < 2 * kRounds; ++k) patch_piece(d, k);
   };
 
   // ---- this lane's pixel in each of the M-tiles (shared by all waves)
@@ -712,7 +729,10 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
 
   // A pair of M-tiles (2 mp, 2 mp + 1): 72 steps (tap, g) of two pixel-fragment reads (two steps ahead) and two MFMAs
   // with the same weight fragment; the pieces of the previous pair are spread over steps 3, 10, .., 66.
-  auto mpair = [&](const unsigned char *buf, int mp, f32x16 (&acc)[2], const f32x16 (&prev)[2], const unsigned (&prev_off)[2]) {
+  // (`dma`: the next tile's patch rides on this pair's first steps -- all of its operations in FRONT of the step that issues the
+  //  previous pair's first stores, so that the counted wait at the tile's end still leaves exactly that many stores in flight)
+  auto mpair = [&](const unsigned char *buf, int mp, f32x16 (&acc)[2], const f32x16 (&prev)[2], const unsigned (&prev_off)[2], bool carry,
+                   const PatchDma &dma) {
     u32x4 px[4][2];
     unsigned tb[2] = {0u, 0u};
     auto rd = [&](int s) {
@@ -738,9 +758,21 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
       if constexpr (s + 3 < 72) rd(s + 3);
       if constexpr (s >= 3 && s < 70 && (s - 3) % 7 == 0) epi_piece(prev, (s - 3) / 7, prev_off);
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m) {
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr[s]), __builtin_bit_cast(bf16x8, px[s & 3][m]),
                                                          acc[m], 0, 0, 0);
+        // stride 1: an operation behind the first MFMA of steps 4, 6, .., 26; stride 2: behind both MFMAs of steps 4 .. 13 -- all
+        // before step 31, where the previous pair's first two stores are issued
+        if constexpr (S2) {
+          if constexpr (s >= 4 && s < 4 + kRounds) {
+            if (carry) patch_piece(dma, 2 * (s - 4) + m);
+          }
+        } else {
+          if constexpr (s >= 4 && s < 4 + 4 * kRounds && (s & 1) == 0) {
+            if (carry && m == 0) patch_piece(dma, (s - 4) >> 1);
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -765,9 +797,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
     auto step = [&](f32x16 (&cur)[2], const f32x16 (&prev)[2], const unsigned (&prev_off)[2], unsigned (&cur_off)[2]) {
       __builtin_amdgcn_s_barrier();    // every wave's share of this patch has landed; nobody still reads the other buffer
       const int tn = t + gridDim.x;
-      if (tn < ntiles) issue_patch(tile_of(tn), nb ^ 1);
+      const PatchDma dma = prep_patch(tile_of(tn < ntiles ? tn : t), nb ^ 1, tn < ntiles);
       const int tt = tile_of(t);
-      mpair(lds + nb * kBuf, 0, cur, prev, prev_off);
+      mpair(lds + nb * kBuf, 0, cur, prev, prev_off, true, dma);
       cur_off[0] = out_off(tt, 0); cur_off[1] = out_off(tt, 1);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                  // the next patch is older than this tile's four stores
       t = tn;
@@ -791,12 +823,12 @@ __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p)
     for (; t < ntiles; t += gridDim.x, nb ^= 1) {
       __builtin_amdgcn_s_barrier();      // every wave's share of this patch has landed; nobody still reads the other buffer
       const int tn = t + gridDim.x;
-      if (tn < ntiles) issue_patch(tile_of(tn), nb ^ 1);
+      const PatchDma dma = prep_patch(tile_of(tn < ntiles ? tn : t), nb ^ 1, tn < ntiles);
       const int tt = tile_of(t);
       const unsigned char *buf = lds + nb * kBuf;
-      mpair(buf, 0, accA, accB, offB);                                    // (B = M-tiles 2, 3 of the previous tile)
+      mpair(buf, 0, accA, accB, offB, true, dma);                         // (B = M-tiles 2, 3 of the previous tile)
       offA[0] = out_off(tt, 0); offA[1] = out_off(tt, 1);
-      mpair(buf, 1, accB, accA, offA);
+      mpair(buf, 1, accB, accA, offA, false, dma);
       offB[0] = out_off(tt, 2); offB[1] = out_off(tt, 3);
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                    // the next patch is older than this iteration's eight stores
     }
