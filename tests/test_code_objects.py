@@ -122,6 +122,18 @@ def test_whole_bottleneck_kernel_budget(md):
             assert codeobj.workgroups_per_cu(r, lds) == 1
 
 
+def test_front_of_layer2_0_kernel_budget(md):
+    """front_s2_kernel (conv1 + stride-2 conv2 of layer2.0 in one launch): 16 + 72 resident weight fragments and the two
+    GEMMs' working sets inside one wave's 512 registers, NO scratch (its counted vmcnt waits name exactly the LDS-DMA pieces
+    the source issues), 151 552 B of dynamic LDS (3 input-row slots + the 3-row line buffer) = one workgroup per CU."""
+    for shift in ('true', 'false'):
+        r = _one(md, f'front_s2_kernel<{shift}>')
+        assert r['.max_flat_workgroup_size'] == 256 and r['.vgpr_count'] <= 512 and r['.agpr_count'] >= 200
+        assert r['.vgpr_count'] - r['.agpr_count'] <= 256
+        assert r['.private_segment_fixed_size'] == 0 and r['.vgpr_spill_count'] == 0
+        assert codeobj.workgroups_per_cu(r, 151552) == 1
+
+
 def test_cross_block_kernel_budget_and_wait_tables(md):
     """conv31_fused_kernel: 8 waves = two per SIMD -> at most 256 registers, NO scratch (a spill would be a vector-memory
     operation its counted waits know nothing about); the dynamic LDS of every instantiation fits one workgroup per CU.  And

@@ -301,6 +301,31 @@ bool conv_bf16_256_valid(const ConvParams &p, int ks) {
 // Needs at least two K-tiles per tile (K >= 128: "kt + 2" must not skip a tile) and Cout <= 2048 (the bias in LDS).
 // Bit-identical to conv_bf16_256 and to conv_igemm's bf16 tiles; the tuner picks per layer.
 // ---------------------------------------------------------------------------------------------
+#ifndef TSM_256P_DMA_IN_MFMA
+#define TSM_256P_DMA_IN_MFMA 0   // measured at config 5: 3x3 launches 250 -> 266 us, conv3 + downsample of layer2.0 540 -> 595 us (anything
+#endif                           // added to the MFMA cluster lengthens the critical path: the other group's memory phase is the shorter one)
+#ifndef TSM_256P_X
+#define TSM_256P_X 0             // timing probes (garbage results): 1 no DMA in the K loop, 2 the DMA reads nothing (dead offsets), 4 one fragment read per step
+#endif
+#ifndef TSM_256P_PAIR
+#define TSM_256P_PAIR 1          // 3x3 arm: two 8-MFMA clusters (k 0-15, k 16-31 of a K-half) per barrier pair instead of one.  Measured at config 5:
+                                 // stride-1 3x3 launches unchanged (253 vs 252 us), the stride-2 one of layer3.0 312 -> 288 us; the 1x1 arms lose
+                                 // 0-3 % (conv3 + downsample of layer2.0 545 -> 562 us) and keep one cluster per pair
+#endif
+template <int N> __device__ __forceinline__ void wait_vmcnt_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+#ifndef TSM_256P_STAMP
+#define TSM_256P_STAMP 0   // diagnostic builds only: per-phase cycle sums of workgroup 0 (s_memtime), printed at the kernel's end (1: conv3 + downsample, 2: 3x3)
+#endif
+#if TSM_256P_STAMP
+#define P256_STAMP(i)                                       \
+  do {                                                      \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+    stamp_acc[i] += _t - stamp_last;                        \
+    stamp_last = _t;                                        \
+  } while (0)
+#else
+#define P256_STAMP(i) do {} while (0)
+#endif
 constexpr size_t kLds256pBytes = 131072 + 8192 + 8 * 2176;   // two operand buffers | bias [<= 2048] fp32 | residual arm: eight [8][68] fp32 sub-slabs
 
 template <int KS, bool SHIFT, bool DUAL> struct Tile256State {
@@ -320,6 +345,9 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
   static_assert(KS == 1 || KS == 3, "1x1 (optionally temporally shifted) and 3x3");
   static_assert(!(RES || DUAL) || (KS == 1 && !SHIFT), "residual / K-concatenated second source: plain 1x1 convs (conv3)");
   static_assert(!(RES && DUAL), "the fused conv3 + downsample GEMM has no residual");
+#if TSM_256P_STAMP
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 buffers x 64 KB | bias [Cout] fp32
   typedef __attribute__((address_space(3))) void lds_void;
   typedef Tile256State<KS, SHIFT, DUAL> State;
@@ -393,7 +421,7 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
 
   // Stage one half-operand of K-tile kt of the tile with state T into buffer `par`: which = 0 A k0-31, 1 B k0-31,
   // 2 A k32-63, 3 B k32-63 (two 1-KiB pieces per wave); dead = kInvalid: zeros, no memory traffic
-  auto stage_of = [&](const State &T, int kt, unsigned par, int which, unsigned dead) {
+  auto stage_of = [&](const State &T, int kt, unsigned par, int which, unsigned dead, int qsel = -1) {   // qsel: one of the two pieces, or both
     const int kh = which >> 1;
     const unsigned kbytes = (unsigned)kt * 128u + (unsigned)kh * 64u;
     unsigned char *dst = lds + par * 65536u + ((which & 1) * 2 + kh) * 16384 + wave * 2048;
@@ -403,7 +431,8 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
     if (which & 1) {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)(dst + q * 1024), 16, (int)(T.b_off[q] | dead), (int)kbytes, 0, 0);
+        if (qsel < 0 || q == qsel)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)(dst + q * 1024), 16, (int)(T.b_off[q] | dead), (int)kbytes, 0, 0);
     } else if (KS == 1) {
       unsigned mp = 0u, mm_ = 0u, m0_ = ~0u;
       if (SHIFT) {
@@ -415,6 +444,7 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
       const bool second = DUAL && kt >= nt1;               // wave-uniform: which source this K-tile comes from
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
+        if (qsel >= 0 && q != qsel) continue;
         unsigned off = T.a_off[q];
         if (SHIFT) off = (T.a_offp[q] & mp) | (T.a_offm[q] & mm_) | (T.a_off[q] & m0_);
         if (DUAL && second)
@@ -429,7 +459,8 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
       const unsigned tap_off = (unsigned)(((ky * p.Wi + kx) * p.C + (kt * 64 - tap * p.C) + kh * 32) * 2);
 #pragma unroll
       for (int q = 0; q < 2; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(dst + q * 1024), 16,
+        if (qsel < 0 || q == qsel)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(dst + q * 1024), 16,
                                                  (int)((((T.a_mask[q] >> tap) & 1u) ? T.a_off[q] + tap_off : kInvalid) | dead), 0, 0, 0);
     }
   };
@@ -483,14 +514,22 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
   int g = 0;                                              // K-tiles done so far: the LDS buffer of a K-tile is its parity
   for (int s = 0; s < my; ++s) {
     const unsigned next_dead = s + 1 < my ? 0u : kInvalid;
+    P256_STAMP(5);
     setup(nxt, s + 1);
+    P256_STAMP(0);
     for (int kt = 0; kt < nt; ++kt, ++g) {
       const unsigned buf = (unsigned)(g & 1) * 65536u;
       // K-tile kt + d of the flat sequence: this tile's, or the first ones of the next tile
-      auto stage = [&](int d, int which) {
+      auto stage = [&](int d, int which, int qsel) {
         const unsigned par = (unsigned)((g + d) & 1);
-        if (kt + d < nt) stage_of(cur, kt + d, par, which, 0u);
-        else stage_of(nxt, kt + d - nt, par, which, next_dead);
+        if (kt + d < nt) stage_of(cur, kt + d, par, which, (TSM_256P_X & 2) ? kInvalid : 0u, qsel);
+        else stage_of(nxt, kt + d - nt, par, which, next_dead, qsel);
+      };
+      auto stage_ph = [&](int ph, int qsel) {
+        if (ph == 0) stage(1, 2, qsel);
+        else if (ph == 1) stage(1, 3, qsel);
+        else if (ph == 2) stage(2, 0, qsel);
+        else stage(2, 1, qsel);
       };
       const bool after_epilogue = kt == 0 && s > 0;       // 16 stores sit between the operands awaited here and the younger DMA
       const bool with_res = RES && kt == nt - 1;          // 8 residual loads sit there (issued right here)
@@ -498,6 +537,53 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
 #pragma unroll
         for (int t = 0; t < 8; ++t) load_res(cur, t, t);
       }
+      constexpr bool kPair = TSM_256P_PAIR != 0 && KS == 3;
+      if constexpr (kPair) {
+        // One barrier pair per K-HALF: the twelve fragment reads and the four DMA pieces of both of its k-16 steps in front of the
+        // first barrier, sixteen MFMAs (the same order as below: k 0-15 then k 16-31 of every accumulator) behind it.  The waits are
+        // those of the odd phases below, behind the same operations.
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+          u32x4 af[2][4], bf[2][2];
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+#if TSM_256P_X & 4     // timing probe: one fragment read per step instead of six (garbage results)
+            if (h2 == 1) { af[1][0] = af[0][0]; af[1][1] = af[0][0]; af[1][2] = af[0][0]; af[1][3] = af[0][0]; bf[1][0] = af[0][0]; bf[1][1] = af[0][0]; continue; }
+            af[0][0] = *reinterpret_cast<const u32x4 *>(lds + buf + pp * 16384u + a_rd0);
+            af[0][1] = af[0][0]; af[0][2] = af[0][0]; af[0][3] = af[0][0]; bf[0][0] = af[0][0]; bf[0][1] = af[0][0];
+            continue;
+#endif
+            const unsigned ra = buf + pp * 16384u + (h2 ? a_rd1 : a_rd0);
+            const unsigned rb = buf + pp * 16384u + (h2 ? b_rd1 : b_rd0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[h2][j] = *reinterpret_cast<const u32x4 *>(lds + rb + j * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[h2][i] = *reinterpret_cast<const u32x4 *>(lds + ra + i * 2048);
+          }
+#if TSM_256P_X & 1     // timing probe: no DMA issued in the K loop (garbage results)
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+          stage_ph(2 * pp, -1);
+          stage_ph(2 * pp + 1, -1);
+          if (after_epilogue) wait_vmcnt_lgkm0<24>();
+          else wait_vmcnt_lgkm0<8>();
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[h2][j]), __builtin_bit_cast(bf16x8, af[h2][i]),
+                                                                    acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+        }
+      } else {
 #pragma unroll
       for (int ph = 0; ph < 4; ++ph) {
         u32x4 af[4], bf[2];
@@ -509,14 +595,16 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
 #pragma unroll
           for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4 *>(lds + ra + i * 2048);
         }
-        if (ph == 0) stage(1, 2);
-        else if (ph == 1) stage(1, 3);
-        else if (ph == 2) stage(2, 0);
-        else stage(2, 1);
+        // The phase's two DMA pieces: in front of the barrier (the other wave group's MFMAs run meanwhile), or -- TSM_256P_DMA_IN_MFMA --
+        // one by one BEHIND this wave's own MFMAs, where issuing a piece costs next to nothing (in a burst in front of a barrier
+        // ~100-150 cycles each: the part of a phase that is not MFMA was longer than the other group's MFMAs).  The phase's wait then
+        // sees two operations fewer behind the operands it waits for.
+        constexpr bool kIn = TSM_256P_DMA_IN_MFMA != 0 && !RES;   // (the residual arm sits at 256 registers: it would spill)
+        if (!kIn) stage_ph(ph, -1);
         if (ph & 1) {
-          if (after_epilogue) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
-          else if (with_res) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+          if (after_epilogue) wait_vmcnt_lgkm0<kIn ? 22 : 24>();
+          else if (with_res) wait_vmcnt_lgkm0<kIn ? 14 : 16>();
+          else wait_vmcnt_lgkm0<kIn ? 6 : 8>();
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -526,15 +614,23 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 2; ++j) {
             acc[i][j] = RES ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]),
                                                                       acc[i][j], 0, 0, 0)
                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bf[j]), __builtin_bit_cast(bf16x8, af[i]),
                                                                       acc[i][j], 0, 0, 0);
+            if (kIn && j == 1 && (i == 0 || i == 2)) {
+              __builtin_amdgcn_sched_barrier(0);
+              stage_ph(ph, i >> 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
       }
+      }
+      P256_STAMP((kt == 0 ? 1 : kt == 1 ? 2 : 3));
     }
     // ---- epilogue of tile s: the next tile's first operands are in flight ----
     if constexpr (!RES) {   // from registers (no LDS, no barrier)
@@ -569,7 +665,11 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq) {
             const u32x4 ov = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
+#ifdef TSM_256P_NOSTORE   // probe: the stores fall outside the window (no memory traffic)
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rsrcY, (int)((unsigned)o | kInvalid), j * 64 + qq * 16, TSM_AUX_256);
+#else
             __builtin_amdgcn_raw_buffer_store_b128(ov, rsrcY, o, j * 64 + qq * 16, TSM_AUX_256);
+#endif
           }
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
@@ -610,8 +710,14 @@ __global__ void __launch_bounds__(512, 1) conv_bf16_256p_kernel(const ConvParams
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     }
+    P256_STAMP(4);
     cur = nxt;
   }
+#if TSM_256P_STAMP
+  if (((TSM_256P_STAMP == 1 && DUAL) || (TSM_256P_STAMP == 2 && KS == 3)) && bid == 0 && (tid == 0 || tid == 256))
+    printf("256p KS=%d DUAL=%d wave %d tiles=%d nt=%d: setup %llu ktile0 %llu ktile1 %llu ktiles2+ %llu epilogue %llu other %llu cycles\n", KS, (int)DUAL,
+           wave, my, nt, stamp_acc[0], stamp_acc[1], stamp_acc[2], stamp_acc[3], stamp_acc[4], stamp_acc[5]);
+#endif
   if (wm == 0) __builtin_amdgcn_s_barrier();              // the early group waits for the delayed one
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the dead tail stages (zeros) land before the workgroup leaves its LDS
 }

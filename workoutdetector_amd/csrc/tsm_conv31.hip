@@ -490,6 +490,10 @@ __global__ void __launch_bounds__(512, 2) conv31_fused_kernel(const Conv31Params
 #ifndef TSM_C31P_QSPLIT
 #define TSM_C31P_QSPLIT 0  // GEMM2 MFMAs a consumer issues in front of barrier B (measured: 0 / 8 / 16 within 2 %, 0 best)
 #endif
+#ifndef TSM_C31P_SPREAD
+#define TSM_C31P_SPREAD 0  // 1: the consumers' weight pieces ride one by one behind GEMM2's MFMAs instead of in two bursts (measured with
+                           // QSPLIT 16: 366 -> 391 us per layer3 site -- the producers wait for W3 at the next A, the bursts land it sooner)
+#endif
 template <int K3, int C, int N1> struct C31P {
   static constexpr int M = 128, NT = 512;
   static constexpr int KT1 = K3 / 16;              // k16 steps of GEMM1
@@ -783,18 +787,24 @@ __global__ void __launch_bounds__(512, 2) conv31_pc_kernel(const Conv31Params p)
     }
     const __amdgpu_buffer_rsrc_t rsrcW3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w3), 0, C * K3 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w1), 0, N1 * C * 2, 0x00020000);
+    auto w3_piece = [&](int nc, unsigned dead, int i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW3, (lds_void *)(lds + L::kW3 + (rg * L::NW3 + i) * 1024), 16,
+                                               (int)(w3off[i] | dead), nc * 64 * rb3, 0, 0);
+    };
+    auto w1_piece = [&](int nc, unsigned buf, unsigned dead, int i) {    // buf: byte offset of the W1 buffer
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW1, (lds_void *)(lds + L::kW1 + buf + (rg * L::NW1 + i) * 1024), 16,
+                                               (int)(w1off[i] | dead), nc * 128, 0, 0);
+    };
     auto issue_w3 = [&](int nc, unsigned dead) {
 #pragma unroll
-      for (int i = 0; i < L::NW3; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW3, (lds_void *)(lds + L::kW3 + (rg * L::NW3 + i) * 1024), 16,
-                                                 (int)(w3off[i] | dead), nc * 64 * rb3, 0, 0);
+      for (int i = 0; i < L::NW3; ++i) w3_piece(nc, dead, i);
     };
-    auto issue_w1 = [&](int nc, unsigned buf, unsigned dead) {           // buf: byte offset of the W1 buffer
-#pragma unroll
-      for (int i = 0; i < L::NW1; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW1, (lds_void *)(lds + L::kW1 + buf + (rg * L::NW1 + i) * 1024), 16,
-                                                 (int)(w1off[i] | dead), nc * 128, 0, 0);
-    };
+    // TSM_C31P_SPREAD: W1's pieces ride behind the GEMM2 MFMAs in front of barrier B, W3's behind the ones after it (a slot
+    // without a chunk to multiply issues them at once); the default issues each set in one burst
+    constexpr int NMq = 4 * L::NTL2;
+    constexpr bool SPREAD = TSM_C31P_SPREAD != 0;
+    constexpr int W1E = SPREAD && L::QSPLIT >= L::NW1 ? L::QSPLIT / L::NW1 : 0, W1D = W1E > 0 ? W1E : 1;               // MFMAs per W1 piece
+    constexpr int W3E = SPREAD && NMq - L::QSPLIT >= L::NW3 ? (NMq - L::QSPLIT) / L::NW3 : 0, W3D = W3E > 0 ? W3E : 1;   // ... per W3 piece
     f32x16 acc2[L::NTL2];
 #pragma unroll
     for (int j = 0; j < L::NTL2; ++j)
@@ -814,7 +824,7 @@ __global__ void __launch_bounds__(512, 2) conv31_pc_kernel(const Conv31Params p)
       C31P_STAMP(4);
       __builtin_amdgcn_s_barrier();                                        // A: LDS tile (g - 1) & 1 is written, W3 / W1 pieces of the last slot have landed
       C31P_STAMP(0);
-      issue_w1(kp, par * (unsigned)(N1 * 128), live_p ? 0u : kInvalid);    // W1's chunk kp -> buffer g & 1 (free: read two slots ago)
+      const unsigned w1buf = par * (unsigned)(N1 * 128), w1dead = live_p ? 0u : kInvalid;   // W1's chunk kp -> buffer g & 1 (free: read two slots ago)
       // ---- GEMM2 of chunk kc: t1 += shift(y chunk) * W1[:, chunk]^T, from LDS tile / W1 buffer (g - 1) & 1 ----
       const unsigned prev = (par ^ 1u);
       const int c0ch = kc * 64;
@@ -840,16 +850,20 @@ __global__ void __launch_bounds__(512, 2) conv31_pc_kernel(const Conv31Params p)
             ring[m % D] = *reinterpret_cast<const u32x4 *>(lds + (bb ^ (unsigned)(((m + D) / L::NTL2) << 5)) + ((m + D) % L::NTL2) * 32 * 128);
           acc2[m % L::NTL2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4[m / L::NTL2]), __builtin_bit_cast(bf16x8, b),
                                                                       acc2[m % L::NTL2], 0, 0, 0);
+          if (W1E > 0 && m % W1D == 0 && m / W1D < L::NW1) w1_piece(kp, w1buf, w1dead, m / W1D);
           __builtin_amdgcn_sched_barrier(0);
         }
+      }
+      if (!have || W1E == 0) {
+#pragma unroll
+        for (int i = 0; i < L::NW1; ++i) w1_piece(kp, w1buf, w1dead, i);
       }
       C31P_STAMP(1);
       __builtin_amdgcn_s_barrier();                                        // B: the producers have read W3's chunk kp
       C31P_STAMP(2);
-      {
-        const int kn = kp + 1 == L::NC ? 0 : kp + 1;
-        issue_w3(kn, g + 1 < nslots ? 0u : kInvalid);                      // W3's chunk of the NEXT slot
-      }
+      const int kn = kp + 1 == L::NC ? 0 : kp + 1;                         // W3's chunk of the NEXT slot
+      const unsigned w3dead = g + 1 < nslots ? 0u : kInvalid;
+      if (!have || W3E == 0) issue_w3(kn, w3dead);
       if (have) {
 #pragma unroll
         for (int m = L::QSPLIT; m < NM; ++m) {
@@ -858,6 +872,7 @@ __global__ void __launch_bounds__(512, 2) conv31_pc_kernel(const Conv31Params p)
             ring[m % D] = *reinterpret_cast<const u32x4 *>(lds + (bb ^ (unsigned)(((m + D) / L::NTL2) << 5)) + ((m + D) % L::NTL2) * 32 * 128);
           acc2[m % L::NTL2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a4[m / L::NTL2]), __builtin_bit_cast(bf16x8, b),
                                                                       acc2[m % L::NTL2], 0, 0, 0);
+          if (W3E > 0 && (m - L::QSPLIT) % W3D == 0 && (m - L::QSPLIT) / W3D < L::NW3) w3_piece(kn, w3dead, (m - L::QSPLIT) / W3D);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
