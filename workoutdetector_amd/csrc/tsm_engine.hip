@@ -118,6 +118,7 @@ struct tsm_engine {
   // Tuning hooks, read ONCE in tsm_create (never per launch): TSM_CONV_TILE=<name> forces one tile shape wherever it
   // is valid, TSM_CONV_CODE=<int> one tile code (tile | 0x100 = split-K form); tests and tools/ sweeps only.
   int force_tile = 0, force_code = -1;
+  int tail_split = 1;   // TSM_TAIL_SPLIT=0: the tuner does not try the tail-split form (tile code bit 0x200)
   // Consecutive conv launches walk their output tiles in opposite directions: a kernel starts with the rows its
   // predecessor wrote last, which are still in the Infinity Cache / L2 (bit-neutral; -1...2 % forward time in the
   // HBM-bound formats, nothing in fp32).  TSM_ZIGZAG=0 switches it off.
@@ -281,6 +282,23 @@ void tune_cache_store(tsm_engine *e, int key, const std::vector<int> &codes) {
   fclose(f);
 }
 
+// The tail split of a segmented 64x64 launch (ConvParams::ksplit = 2, tile code bit 0x200): the conv_igemm SEG kernel keeps five
+// workgroups per CU resident, so a launch runs in rounds of 5 * n_cu tiles; when the last round is less than ~85 % full, its
+// tiles -- rounded to whole rows of tiles -- run as (tile, K segment) pieces.  False when there is no whole round, no
+// remainder worth splitting, or the segment sums do not fit the scratch buffer.
+bool tail_split_from(const tsm::ConvParams &p, int n_cu, size_t partial_elems, int *tail_from) {
+  if (p.kseg_len <= 0 || p.Cout % 64 != 0 || n_cu <= 0) return false;
+  const long ntn = p.Cout / 64, ntm = ((long)p.M + 63) / 64, tiles = ntm * ntn, slots = 5L * n_cu;
+  const long rounds = tiles / slots, rem = tiles - rounds * slots;
+  if (rounds < 1 || rem == 0 || rem * 100 > slots * 85) return false;
+  const long from = rounds * slots / ntn * ntn;            // whole rows of tiles
+  if (from <= 0 || from >= tiles) return false;
+  const size_t tail_rows = (size_t)p.M - (size_t)(from / ntn) * 64;
+  if ((size_t)tsm::conv_num_segments(p) * tail_rows * (size_t)p.Cout > partial_elems) return false;
+  *tail_from = (int)from;
+  return true;
+}
+
 struct Tap {
   const float *ptr = nullptr;
   int64_t shape[4] = {0, 0, 0, 0};
@@ -363,13 +381,31 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
         st = tsm::launch_splitk_reduce(e->d_partial, tsm::conv_num_segments(p), p.M, p.Cout, p.bias, nullptr, y, p.relu, s);
       return st;
     }
+    // 0x200: the tail split (ConvParams::ksplit = 2) of a segmented 64x64 layer -- the tiles of the last, partly filled round of
+    // resident workgroups (five per CU) as (tile, segment) pieces.  Re-derived from THIS launch's tile count on every launch;
+    // whenever it does not apply the whole-K form runs (same bits).
+    if ((code & 0x200) && (code & 15) == tsm::kTile64x64 && p.kseg_len > 0) {
+      int tail_from = 0;
+      if (tail_split_from(p, e->n_cu, e->partial_elems, &tail_from)) {
+        float *y = p.y;
+        const int mt0 = tail_from / (p.Cout / 64) * 64;
+        p.ksplit = 2;
+        p.tail_from = tail_from;
+        p.ypart = e->d_partial;
+        hipError_t st = tsm::launch_conv(p, ks, s);
+        if (st == hipSuccess)
+          st = tsm::launch_splitk_reduce(e->d_partial, tsm::conv_num_segments(p), p.M - mt0, p.Cout, p.bias, nullptr,
+                                         y + (size_t)mt0 * p.Cout, p.relu, s);
+        return st;
+      }
+    }
     return tsm::launch_conv(p, ks, s);
   };
   // A code read from TSM_TUNE_CACHE (or forced through the environment) is only trusted after it has been checked
   // against THIS layer: anything else falls back to the heuristic shape, so a stale, foreign or hand-edited cache
   // line can only cost speed.
   auto code_ok = [&](const tsm::ConvParams &p, int code) {
-    return code > 0 && (code & ~0x3D0F) == 0 && tsm::conv_tile_valid(p, code & 15);   // (0x400 / 0x800 / 0x1000 / 0x2000: conv2 + conv3 / the whole block / conv3 + the next block's conv1 / conv1 + the stride-2 conv2 run fused, below)
+    return code > 0 && (code & ~0x3F0F) == 0 && tsm::conv_tile_valid(p, code & 15);   // (0x400 / 0x800 / 0x1000 / 0x2000: conv2 + conv3 / the whole block / conv3 + the next block's conv1 / conv1 + the stride-2 conv2 run fused, below)
   };
   int flip = 0;   // alternates the tile walk direction of consecutive conv launches (ConvParams::reverse)
   auto conv = [&](int idx, tsm::ConvParams p, int ks, bool is3x3) -> int {
@@ -394,6 +430,8 @@ int run_forward(tsm_engine *e, const float *d_clips, int layout, int n_clips, fl
         cands.push_back(t);
         if (need <= e->partial_elems && tiles64 < 4L * e->n_cu) cands.push_back(t | 0x100);
       }
+      int tail_from = 0;
+      if (e->tail_split && tail_split_from(p, e->n_cu, e->partial_elems, &tail_from)) cands.push_back((int)tsm::kTile64x64 | 0x200);
     } else {
       for (int t = 1; t < tsm::kNumTiles; ++t)
         if (tsm::conv_tile_valid(p, t)) cands.push_back(t);
@@ -858,6 +896,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
   if (const char *f31 = getenv("TSM_FUSE_C3C1")) e->fuse31 = atoi(f31) != 0;
   if (const char *ff = getenv("TSM_FUSE_FRONT")) e->fuse_front = atoi(ff) != 0;
   if (const char *zz = getenv("TSM_ZIGZAG")) e->zigzag = atoi(zz) != 0;
+  if (const char *ts = getenv("TSM_TAIL_SPLIT")) e->tail_split = atoi(ts) != 0;
   // TSM_TUNE_CACHE=<file> names the tune cache; unset: a per-user default ($XDG_CACHE_HOME or $HOME/.cache, then
   // tsm_hip/tune_cache.txt), so that the second process on a machine pays no tuning pass; "", "0" or "off" disables it.
   {
@@ -890,7 +929,7 @@ int tsm_create(const tsm_config *cfg, tsm_engine **out) {
                   " T" + std::to_string(cfg->num_segments) + " " + std::to_string(cfg->height) + "x" +
                   std::to_string(cfg->width) + " dtype" + std::to_string(cfg->dtype) + " shift" +
                   std::to_string(cfg->is_shift ? cfg->shift_div : 0) + " fuse" + std::to_string(e->fuse_down ? 1 : 0) + "/" + std::to_string(e->fuse23) + "/" + std::to_string(e->fuse_block) + "/" + std::to_string(e->fuse31) + "/" + std::to_string(e->fuse_front) +
-                  " zz" + std::to_string(e->zigzag ? 1 : 0) + " stem" + std::to_string(e->stem_direct ? 1 : 0) +
+                  " zz" + std::to_string(e->zigzag ? 1 : 0) + " tk" + std::to_string(e->tail_split ? 1 : 0) + " stem" + std::to_string(e->stem_direct ? 1 : 0) +
                   std::to_string(e->stem_pool ? 1 : 0) + std::to_string(e->stem_planar ? 1 : 0);
   }
   *out = e;

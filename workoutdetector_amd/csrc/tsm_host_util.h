@@ -158,7 +158,7 @@ inline bool parse_tune_line(const char *line, const std::string &want, int num_t
     char *end = nullptr;
     const long v = strtol(q, &end, 10);
     if (end == q) return false;
-    if (v < 0 || (v & ~0x3D0FL) != 0 || (int)(v & 15) >= num_tiles) return false;
+    if (v < 0 || (v & ~0x3F0FL) != 0 || (int)(v & 15) >= num_tiles) return false;
     got.push_back((int)v);
     if (*end == ',') q = end + 1;
     else if (*end == '\n' || *end == 0) q = end;

@@ -89,15 +89,24 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && BM == 64) ? 5 : 1) con
 
   // XCD-aware bijective remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
   // contiguous run of tiles, n fastest, so co-resident blocks re-use the same A panel from L2.
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int bid = blockIdx.x;
+  const bool tail_mode = SEG && p.ksplit == 2;            // whole tiles first, then (tile, segment) pieces of the last rows of tiles
+  const bool in_tail = tail_mode && bid >= p.tail_from;
+  const int nwg = tail_mode ? p.tail_from : (int)gridDim.x;   // (the remap covers the whole tiles; the pieces go round-robin over the XCDs)
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   if (p.reverse) tile = nwg - 1 - tile;   // walk the tiles from the far end (ConvParams::reverse)
-  int seg = 0;  // SEG + ksplit: the grid holds ntm * ntn tiles per K segment, segment-major
-  if (SEG && p.ksplit) {
+  int seg = 0;  // SEG + ksplit = 1: the grid holds ntm * ntn tiles per K segment, segment-major
+  if (SEG && p.ksplit == 1) {
     seg = tile / (p.ntm * p.ntn);
     tile -= seg * (p.ntm * p.ntn);
   }
+  if (in_tail) {
+    const int u = bid - p.tail_from, n_tail = p.ntm * p.ntn - p.tail_from;
+    seg = u / n_tail;
+    tile = p.tail_from + (u - seg * n_tail);
+  }
+  const bool split_wg = SEG && (p.ksplit == 1 || in_tail);   // this workgroup multiplies ONE K segment and writes raw sums
   const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -432,7 +441,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && BM == 64) ? 5 : 1) con
   // buf[kt&1] before the next barrier.  The body is straight-line.
   // This workgroup multiplies K-steps [kt0, nk): all of K, or one segment of it (SEG + ksplit).
   int kt0 = 0, nk = p.Kp / KC;
-  if (SEG && p.ksplit) {
+  if (split_wg) {
     kt0 = seg * p.kseg_len;
     nk = kt0 + p.kseg_len < nk ? kt0 + p.kseg_len : nk;
   }
@@ -611,11 +620,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (SEG && BM == 64) ? 5 : 1) con
 
   // Stores go through a descriptor that ends at row M: rows past the end are dropped by the range
   // check, which keeps the epilogue branch-free (no per-pass wait on earlier stores).
-  const bool partial = SEG && p.ksplit;  // raw segment sums to y = partial[seg][M][Cout]: no bias, no ReLU
+  const bool partial = split_wg;  // raw segment sums to y = partial[seg][M][Cout] (tail split: ypart = partial[seg][tail rows][Cout]): no bias, no ReLU
   const size_t y_bytes = ((size_t)p.M - m0) * p.Cout * EB;
+  const int mt0 = in_tail ? (p.tail_from / p.ntn) * BM : 0;   // first row of the tail
+  char *ybase = in_tail ? reinterpret_cast<char *>(p.ypart) + ((size_t)seg * (p.M - mt0) + (m0 - mt0)) * p.Cout * EB
+                        : reinterpret_cast<char *>(p.y) + ((size_t)(partial ? seg : 0) * p.M + m0) * p.Cout * EB;
   const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<char *>(p.y) + ((size_t)(partial ? seg : 0) * p.M + m0) * p.Cout * EB, 0,
-      (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
+      ybase, 0, (int)(y_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : y_bytes), 0x00020000);
   const float floor_ = (p.relu && !partial) ? 0.f : -INFINITY;  // ReLU as a branch-free clamp
   if constexpr (BF) {
     const f32x4 bias0 = *reinterpret_cast<const f32x4 *>(p.bias + n0 + ecol);
@@ -697,7 +708,10 @@ static hipError_t launch_conv_seg(ConvParams p, hipStream_t s) {
   } else {
     p.ntm = (p.M + BM - 1) / BM;
     p.ntn = p.Cout / BN;
-    const dim3 grid((unsigned)(p.ntm * p.ntn * (p.ksplit ? conv_num_segments(p) : 1)));
+    const int ntiles = p.ntm * p.ntn;
+    if (p.ksplit == 2 && (!p.ypart || p.tail_from <= 0 || p.tail_from >= ntiles || p.tail_from % p.ntn != 0)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(p.ksplit == 2 ? p.tail_from + (ntiles - p.tail_from) * conv_num_segments(p)
+                                             : ntiles * (p.ksplit ? conv_num_segments(p) : 1)));
     const dim3 block(64 * WGM * WGN);
     if constexpr (KS == 1 && !SHIFT) {
       if (p.x2) {
@@ -834,7 +848,7 @@ hipError_t launch_conv(const ConvParams &p_in, int ks, hipStream_t s) {
     return hipErrorInvalidValue;
   if (p.prec != kPrecF32 && p.prec != kPrecBf16x3 && p.prec != kPrecBf16) return hipErrorInvalidValue;
   if (p.kseg_len < 0 || (p.kseg_len > 0 && (p.prec != kPrecF32 || p.res || ks == 7))) return hipErrorInvalidValue;
-  if (p.ksplit && p.kseg_len <= 0) return hipErrorInvalidValue;
+  if ((p.ksplit && p.kseg_len <= 0) || p.ksplit < 0 || p.ksplit > 2) return hipErrorInvalidValue;
   if (p.prec != kPrecF32 && p.T > 0 && p.fold % 8 != 0) return hipErrorInvalidValue;
   // stem: 4 channels per pixel (3 + a zero); the bf16 formats read pixel pairs, which needs stride 2 / pad 3
   if (ks == 7 && (p.C != 4 || (p.prec != kPrecF32 && (p.stride != 2 || p.pad != 3)))) return hipErrorInvalidValue;

@@ -36,8 +36,15 @@ struct ConvParams {
   // workgroup per tile (ksplit = 0) or as one workgroup per (tile, segment) writing raw partial tiles to
   // y = partial[segment][M][Cout] (ksplit = 1; splitk_reduce then applies bias / residual / ReLU) with
   // bit-identical results: split-K for small batches without giving up batch invariance.
+  // ksplit = 2 ("tail split"): output tiles [0, tail_from) run whole-K as with ksplit = 0 and write y; the tiles from
+  // tail_from on (a multiple of ntn: whole rows of tiles, i.e. the rows from (tail_from / ntn) * BM to M) run as
+  // (tile, segment) workgroups writing ypart = partial[segment][tail rows][Cout], reduced like ksplit = 1's.  For a batch
+  // whose tile count leaves the last round of resident workgroups mostly empty: the remainder is spread over the chip in
+  // pieces of one K segment.  Same bits as ksplit = 0 / 1.
   int kseg_len;
   int ksplit;
+  int tail_from;
+  float *ypart;
   // Walk the output tiles from the last one to the first.  The engine alternates this between consecutive launches:
   // a kernel that starts with the rows its predecessor wrote LAST finds them in the 256-MB Infinity Cache / L2.
   int reverse;

@@ -231,13 +231,14 @@ class TsmEngine:
     @classmethod
     def tile_name(cls, code: int) -> str:
         """``tile + 256 * split``: '64x64/splitK' = one workgroup per (tile, K segment), combined in segment order
-        (segmented fp32 layers at small batch); '+conv3' on a block's conv2 = conv2 + conv3 + residual run as one fused
+        (segmented fp32 layers at small batch); '64x64/tailK' = only the tiles of the last, partly filled round of resident
+        workgroups run that way (ConvParams::ksplit = 2); '+conv3' on a block's conv2 = conv2 + conv3 + residual run as one fused
         kernel (the conv3 entry of that block is then unused); '+block' on a block's conv1 = the whole Bottleneck runs as one
         launch (bf16 layer1.1 / layer1.2; the conv2 / conv3 entries are then unused); '+conv1' on a block's conv3 = that
         launch also runs the NEXT block's shift + conv1 (bf16 layer2: conv31_fused_kernel; the next block's conv1 entry is then
         unused); '+conv2' on a block's conv1 = that launch also runs the block's stride-2 conv2 (bf16 layer2.0: front_s2_kernel; the
         conv2 entry is then unused)."""
-        return (cls.TILE_NAMES[code & 15] + ('/splitK' if code & 0x100 else '') + ('+conv3' if code & 0x400 else '') +
+        return (cls.TILE_NAMES[code & 15] + ('/splitK' if code & 0x100 else '') + ('/tailK' if code & 0x200 else '') + ('+conv3' if code & 0x400 else '') +
                 ('+block' if code & 0x800 else '') + ('+conv1' if code & 0x1000 else '') + ('+conv2' if code & 0x2000 else ''))
 
     def conv_tiles(self, n_clips: int) -> Dict[str, str]:
