@@ -40,13 +40,16 @@ static void fuzz_tune_lines(unsigned seed, int rounds) {
     const std::string line = want + "2054,1030,6,3075,4102\n";       // (4102 = 6 | 0x1000: conv3 also runs the next block's conv1)
     EXPECT(parse_tune_line(line.c_str(), want, kNumTiles, &codes));
     EXPECT(codes[0] == (6 | 0x800) && codes[1] == (6 | 0x400) && codes[2] == 6 && codes[3] == (3 | 0x400 | 0x800) && codes[4] == (6 | 0x1000));
+    const std::string line2 = want + "515,8198,3,3,3\n";             // (515 = 3 | 0x200: tail split; 8198 = 6 | 0x2000: conv1 also runs the stride-2 conv2)
+    EXPECT(parse_tune_line(line2.c_str(), want, kNumTiles, &codes));
+    EXPECT(codes[0] == (3 | 0x200) && codes[1] == (6 | 0x2000));
   }
   const char *bad[] = {"", "\n", "|", "abi3", "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|",
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3",            // too few
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,3,3",        // too many
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,9",          // tile out of range
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,35",         // reserved bits set
-                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,8195",       // a bit above the fusion bits
+                       "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,16387",      // a bit above the fusion bits
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,-1",
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,3,3,3,99999999999999999999999999",
                        "abi3 gfx950 T8 224x224 dtype0 shift8 fuse1|256|3,,3,3,3",

@@ -413,7 +413,7 @@ def test_weight_stationary_1x1_wide_equals_the_igemm_tiles_bitwise(hip_lib, monk
 @pytest.mark.parametrize('h,w,b', [(256, 256, 2), (224, 224, 2), (90, 70, 3)])
 def test_weight_stationary_kernels_forced_everywhere_equal_the_igemm_engine_bitwise(hip_lib, sd0, monkeypatch, h, w, b):
     """An engine with TSM_CONV_TILE=ws (every layer that has a weight-stationary form runs it: conv1 / conv2 of layer1,
-    conv3 + downsample of layer1.0 as the K-concatenated GEMM, conv1 / conv2 of layer2, conv1 of layer3.0) against one
+    conv3 + downsample of layer1.0 and of layer2.0 as the K-concatenated GEMM, conv1 / conv2 of layer2, conv1 of layer3.0) against one
     forced onto the 64x64 tile: block outputs and logits bit for bit."""
     from workoutdetector_amd.engine import TsmEngine, launch_trace
     x = make_input(300 + h, b, 8, h, w)
@@ -429,7 +429,8 @@ def test_weight_stationary_kernels_forced_everywhere_equal_the_igemm_engine_bitw
         eng.close()
         ws_families = ('conv3x3_ws_kernel<false>', 'conv3x3_ws128_kernel<false>', 'conv3x3_ws128_kernel<true>', 'conv1x1_ws_kernel<64>',
                        'conv1x1_ws_kernel<256>', 'conv1x1_wsn_kernel<128, 256, true>', 'conv1x1_wsn_kernel<256, 128, false>',
-                       'conv1x1_wsn_kernel<512, 128, false>', 'conv1x1_wsn_kernel<512, 256, false>')
+                       'conv1x1_wsn_kernel<512, 128, false>', 'conv1x1_wsn_kernel<512, 256, false>',
+                       'conv1x1_wsn_kernel<384, 256, true, 2>')     # (conv3 + downsample of layer2.0: two output-channel halves on workgroup pairs)
         for fam in ws_families:      # every weight-stationary form has a layer of ResNet-50 it applies to
             assert tr.ran(fam) == (tile == 'ws'), (tile, fam, sorted(set(tr.kernels)))
     for a, c in zip(got['ws'], got['64x64']):

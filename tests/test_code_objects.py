@@ -88,7 +88,8 @@ def test_weight_stationary_kernels_own_a_whole_register_file(md):
     #  architectural VGPRs, build.EXTRA_FLAGS, so the accumulators no longer count here)
     for name, lds, agprs in (('conv3x3_ws_kernel<false>', 2 * 46 * 1024, 200), ('conv3x3_ws_kernel<true>', 162048, 200),
                              ('conv3x3_ws128_kernel<false>', 150000, 200), ('conv3x3_ws128_kernel<true>', 2 * 8 * 289 * 32 + 512, 200),
-                             ('conv1x1_wsn_kernel<512, 256, false>', 2 * 65536 + 1024, 160)):
+                             ('conv1x1_wsn_kernel<512, 256, false, 1>', 2 * 65536 + 1024, 160),
+                             ('conv1x1_wsn_kernel<384, 256, true, 2>', 2 * 24 * 2048 + 1024, 96)):
         r = _one(md, name)
         assert r['.max_flat_workgroup_size'] == 256 and r['.vgpr_count'] <= 512 and r['.agpr_count'] >= agprs
         assert r['.private_segment_fixed_size'] == 0

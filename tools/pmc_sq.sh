@@ -1,5 +1,5 @@
 #!/bin/bash
-export TSM_TUNE_CACHE=off   # a profiler run never writes (or reads) the per-user tune cache: serialised dispatches favour the one-launch forms
+export TSM_TUNE_CACHE=${TSM_TUNE_CACHE:-off}   # a profiler run never writes (or reads) the per-user tune cache: serialised dispatches favour the one-launch forms; profile_all.sh hands every pass of a mode the private cache file its kernel-trace pass wrote, so that all passes run ONE schedule
 # SQ counters (MFMA pipe busy, LDS activity, clock) per conv launch of the last forward:
 #   bash tools/pmc_sq.sh <tag> <bench args...>     -> gpurun_out/pmc_sq_<tag>.txt
 set -e

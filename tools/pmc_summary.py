@@ -26,7 +26,7 @@ def main(cc_path, kt_path):
     lo, hi = ids[starts[-2]], ids[starts[-1]]
     cols = None
     for d in ids:
-        if not (lo <= d < hi) or not ('conv' in names[d] or 'stem_' in names[d] or 'bneck' in names[d]):
+        if not (lo <= d < hi) or not ('conv' in names[d] or 'stem_' in names[d] or 'bneck' in names[d] or 'front_s2' in names[d]):
             continue
         c = per[d]
         if cols is None:

@@ -1,5 +1,5 @@
 #!/bin/bash
-export TSM_TUNE_CACHE=off   # a profiler run never writes (or reads) the per-user tune cache: serialised dispatches favour the one-launch forms
+export TSM_TUNE_CACHE=${TSM_TUNE_CACHE:-off}   # a profiler run never writes (or reads) the per-user tune cache: serialised dispatches favour the one-launch forms; profile_all.sh hands every pass of a mode the private cache file its kernel-trace pass wrote, so that all passes run ONE schedule
 # HBM traffic passes (FETCH_SIZE, WRITE_SIZE in separate runs, MI355X_MICROARCH.md "HBM") for one bench mode.
 #   bash tools/pmc_traffic.sh <tag> <bench args...>      (run on the GPU box from the repo root)
 #   DOMINANT="<kernel name>" UPDATE="B T H W" bash tools/pmc_traffic.sh ...   also writes profiles/traffic.json (sha-stamped)

@@ -1011,8 +1011,13 @@ struct WsnParams {
   int Hi2, Wi2, stride2;     // DUAL: second source [N, Hi2, Wi2, CIN - K1]
 };
 
-template <int CIN, int COUT, bool DUAL>
+// NSPLIT = 2: the launch computes 2 * COUT output channels, one half per workgroup.  Workgroups b and b + 8 -- neighbours on ONE XCD, so
+// the second read of a pixel tile comes from that XCD's L2 -- walk the same pixel tiles in the same order, each with its half of
+// the weights in registers (conv3 + downsample of layer2.0: 128 + 256 -> 512 channels, 2 x 48 fragments per wave).
+template <int CIN, int COUT, bool DUAL, int NSPLIT = 1>
 __global__ void __launch_bounds__(256, 1) conv1x1_wsn_kernel(const WsnParams p) {
+  static_assert(NSPLIT == 1 || NSPLIT == 2, "one or two output-channel halves");
+  constexpr int CTOT = COUT * NSPLIT;    // channels of an output row
   constexpr int PX = CIN <= 256 ? 128 : 64;
   constexpr int MT = PX / 32;
   constexpr int NG = CIN / 16;
@@ -1020,7 +1025,7 @@ __global__ void __launch_bounds__(256, 1) conv1x1_wsn_kernel(const WsnParams p) 
   constexpr int PPW = NG / 4;            // planes filled per wave
   constexpr int kPlane = PX * 32;
   constexpr int kBuf = NG * kPlane;      // 64 KB
-  constexpr int kAgpr = NTW * NG > 48 ? NTW * NG - 24 : 0;   // fragments pinned to accumulation registers (the 256-register form)
+  constexpr int kAgpr = NTW * NG > 40 ? NTW * NG - 24 : 0;   // fragments pinned to accumulation registers (the forms with 48 / 64 of them)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x kBuf | bias
   typedef __attribute__((address_space(3))) void lds_void;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1028,20 +1033,23 @@ __global__ void __launch_bounds__(256, 1) conv1x1_wsn_kernel(const WsnParams p) 
   const int half = lane >> 5, l31 = lane & 31;
   const int ntiles = (p.M + PX - 1) / PX;
 
-  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, COUT * CIN * 2, 0x00020000);
+  const int nh = NSPLIT == 2 ? ((int)blockIdx.x >> 3) & 1 : 0;          // this workgroup's half of the output channels
+  const int tfirst = NSPLIT == 2 ? ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x >> 4) : (int)blockIdx.x;
+  const int tstep = NSPLIT == 2 ? (int)gridDim.x >> 1 : (int)gridDim.x;   // (NSPLIT = 2: the grid is a multiple of 16)
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, CTOT * CIN * 2, 0x00020000);
   u32x4 wr[NTW][NG];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
     for (int g = 0; g < NG; ++g)
-      wr[nt][g] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, (((wave * NTW + nt) * 32 + l31) * CIN + g * 16 + half * 8) * 2, 0, 0);
+      wr[nt][g] = __builtin_amdgcn_raw_buffer_load_b128(rsrcW, ((nh * COUT + (wave * NTW + nt) * 32 + l31) * CIN + g * 16 + half * 8) * 2, 0, 0);
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
     for (int g = 0; g < NG; ++g)
       if (nt * NG + g < kAgpr) asm volatile("" : "+a"(wr[nt][g]));
   float *bias_lds = reinterpret_cast<float *>(lds + 2 * kBuf);
-  if (tid < COUT) bias_lds[tid] = p.bias[tid];
+  if (tid < COUT) bias_lds[tid] = p.bias[nh * COUT + tid];
   const float floor_ = p.relu ? 0.f : -INFINITY;
 
   const int hsel = (lane & 1) ^ ((lane >> 4) & 1);
@@ -1092,20 +1100,20 @@ __global__ void __launch_bounds__(256, 1) conv1x1_wsn_kernel(const WsnParams p) 
     }
   };
 
-  const size_t ybytes = (size_t)p.M * COUT * 2;
-  int t = blockIdx.x, nb = 0;
+  const size_t ybytes = (size_t)p.M * CTOT * 2;
+  int t = tfirst, nb = 0;
   if (t < ntiles) issue_tile(p.reverse ? ntiles - 1 - t : t, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  for (; t < ntiles; t += gridDim.x, nb ^= 1) {
+  for (; t < ntiles; t += tstep, nb ^= 1) {
     __builtin_amdgcn_s_barrier();
-    const int tn = t + gridDim.x;
+    const int tn = t + tstep;
     if (tn < ntiles) issue_tile(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
     const int tt = p.reverse ? ntiles - 1 - t : t;
     const unsigned char *buf = lds + nb * kBuf;
     // output window of the tile (rebased: 32-bit offsets whatever M * COUT is)
-    const size_t y0 = (size_t)tt * PX * COUT * 2;
+    const size_t y0 = (size_t)tt * PX * CTOT * 2;
     const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char *>(p.y) + y0, 0, (int)(ybytes - y0 > (size_t)PX * COUT * 2 ? (size_t)PX * COUT * 2 : ybytes - y0), 0x00020000);
+        reinterpret_cast<char *>(p.y) + y0, 0, (int)(ybytes - y0 > (size_t)PX * CTOT * 2 ? (size_t)PX * CTOT * 2 : ybytes - y0), 0x00020000);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int pp = mt * 32 + l31;
@@ -1123,7 +1131,7 @@ __global__ void __launch_bounds__(256, 1) conv1x1_wsn_kernel(const WsnParams p) 
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr[nt][g]), __builtin_bit_cast(bf16x8, px),
                                                             acc[nt], 0, 0, 0);
       }
-      const unsigned yoff = (unsigned)(pp * COUT * 2);                   // (rows past M fall outside the rebased window)
+      const unsigned yoff = (unsigned)(pp * CTOT * 2 + nh * COUT * 2);   // (rows past M fall outside the rebased window)
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
         const int ch0 = (wave * NTW + nt) * 32;
@@ -1156,9 +1164,10 @@ __global__ void __launch_bounds__(256, 1) conv1x1_wsn_kernel(const WsnParams p) 
 bool conv1x1_wsn_valid(const ConvParams &p) {
   if (p.prec != kPrecBf16 || p.stride != 1 || p.pad != 0 || p.Hi != p.Ho || p.Wi != p.Wo || p.res || p.kseg_len != 0) return false;
   if ((double)(128 + 2.0 * p.Hi * p.Wi) * p.C * 2.0 >= 2.0e9) return false;
-  if (p.x2) {   // conv3 + downsample of layer1.0: 64 + 64 -> 256
-    return p.T == 0 && p.C == 64 && p.C2 == 64 && p.K1 == 64 && p.Kp == 128 && p.Cout == 256 &&
-           (double)(128.0 / (p.Hi * p.Wi) + 2.0) * p.Hi2 * p.Wi2 * p.C2 * 2.0 < 2.0e9;
+  if (p.x2) {   // conv3 + downsample of layer1.0: 64 + 64 -> 256; of layer2.0: 128 + 256 -> 512 (two halves of 256)
+    const bool l1 = p.C == 64 && p.C2 == 64 && p.K1 == 64 && p.Kp == 128 && p.Cout == 256;
+    const bool l2 = p.C == 128 && p.C2 == 256 && p.K1 == 128 && p.Kp == 384 && p.Cout == 512 && device_info().n_cu >= 16;
+    return p.T == 0 && (l1 || l2) && (double)(128.0 / (p.Hi * p.Wi) + 2.0) * p.Hi2 * p.Wi2 * p.C2 * 2.0 < 2.0e9;
   }
   if (p.Kp != p.C) return false;
   if (p.T > 0 && (p.N % p.T != 0 || p.fold % 8 != 0 || 2 * p.fold > p.C)) return false;
@@ -1238,7 +1247,11 @@ hipError_t launch_conv1x1_wsn(const ConvParams &p, hipStream_t s) {
   const int ntiles = (p.M + px - 1) / px;
   const dim3 grid((unsigned)(ntiles < n_cu ? ntiles : n_cu)), block(256);
   constexpr size_t kLds = 2 * 65536 + 1024;
-  if (p.x2) TSM_KLAUNCH((conv1x1_wsn_kernel<128, 256, true>), grid, block, kLds, s, q);
+  if (p.x2 && p.Kp == 384) {
+    const int pairs = n_cu >> 4 << 3;                                     // workgroup pairs: a multiple of 8 (b and b + 8 share an XCD)
+    const int np = ntiles < pairs ? (ntiles + 7) / 8 * 8 : pairs;         // (a pair without a tile leaves at once)
+    TSM_KLAUNCH((conv1x1_wsn_kernel<384, 256, true, 2>), dim3((unsigned)(2 * np)), block, 2 * 24 * 2048 + 1024, s, q);
+  } else if (p.x2) TSM_KLAUNCH((conv1x1_wsn_kernel<128, 256, true>), grid, block, kLds, s, q);
   else if (p.C == 256) TSM_KLAUNCH((conv1x1_wsn_kernel<256, 128, false>), grid, block, kLds, s, q);
   else if (p.Cout == 128) TSM_KLAUNCH((conv1x1_wsn_kernel<512, 128, false>), grid, block, kLds, s, q);
   else TSM_KLAUNCH((conv1x1_wsn_kernel<512, 256, false>), grid, block, kLds, s, q);
@@ -1276,6 +1289,7 @@ hipError_t opt_in_ws() {
   opt_in(reinterpret_cast<const void *>(&conv3x3_ws128_kernel<true>), kS2LdsBytes);
   opt_in(reinterpret_cast<const void *>(&conv1x1_ws_kernel<256>), 2 * 16 * 4096 + 256);
   opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<128, 256, true>), 2 * 65536 + 1024);
+  opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<384, 256, true, 2>), 2 * 24 * 2048 + 1024);
   opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<256, 128, false>), 2 * 65536 + 1024);
   opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<512, 128, false>), 2 * 65536 + 1024);
   opt_in(reinterpret_cast<const void *>(&conv1x1_wsn_kernel<512, 256, false>), 2 * 65536 + 1024);
