@@ -1056,58 +1056,78 @@ __global__ void __launch_bounds__(256, 1) conv1x1_wsn_kernel(const WsnParams p) 
   const int C1 = DUAL ? p.K1 : CIN, C2 = CIN - C1;
   const int frame_bytes = p.HW * C1 * 2;
   const int frame2_bytes = DUAL ? p.Hi2 * p.Wi2 * C2 * 2 : 0;
-  auto issue_tile = [&](int t, int b) {
+  // The next tile's operands: prep() computes the tile's windows (scalar) and each lane's row offsets for its MT rounds;
+  // piece(d, b, i, k) issues ONE 1-KiB LDS-DMA instruction (round i, plane PPW wave + k).  The compute loop issues a tile's
+  // MT * PPW pieces one every fourth MFMA step -- a piece in a burst behind the barrier costs ~100 cycles of issue, one behind
+  // an MFMA next to nothing (one wave per SIMD: nothing else would hide it) -- and tile 0's all at once.
+  struct TileDma {
+    const char *px, *px2;
+    int szx, szx2;
+    unsigned own[MT], own2[MT], vmask[MT];     // vmask: bit 0 row valid, bit 1 frame t + 1 exists, bit 2 frame t - 1 exists
+  };
+  auto prep = [&](int t, bool live) {
+    TileDma d;
     const int m0 = t * PX;
     const long base_row = (long)m0 - p.HW;
     const size_t span = (size_t)(PX + 2 * p.HW) * C1 * 2;
-    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.x) + base_row * (long)(C1 * 2)), 0,
-        (int)(span > 0x7FFFFFF0u ? 0x7FFFFFF0u : span), 0x00020000);
+    d.px = reinterpret_cast<const char *>(p.x) + base_row * (long)(C1 * 2);
+    d.szx = (int)(span > 0x7FFFFFF0u ? 0x7FFFFFF0u : span);
     const int n0 = m0 / p.HW;                                           // first frame of the tile
-    const __amdgpu_buffer_rsrc_t rsrcX2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(DUAL ? p.x2 : p.x) + (size_t)n0 * frame2_bytes), 0,
-        DUAL ? (int)((size_t)(PX / p.HW + 2) * frame2_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : (size_t)(PX / p.HW + 2) * frame2_bytes) : 0,
-        0x00020000);
+    d.px2 = reinterpret_cast<const char *>(DUAL ? p.x2 : p.x) + (size_t)n0 * frame2_bytes;
+    d.szx2 = DUAL ? (int)((size_t)(PX / p.HW + 2) * frame2_bytes > 0x7FFFFFF0u ? 0x7FFFFFF0u : (size_t)(PX / p.HW + 2) * frame2_bytes) : 0;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int pl = 32 * i + (lane >> 1);
       const int m = m0 + pl;
-      const bool ok = m < p.M;
+      const bool ok = live && m < p.M;
       const int n = (ok ? m : m0) / p.HW;
       const int tt = p.T > 0 ? n % p.T : 0;
-      const unsigned own = (unsigned)((pl + p.HW) * C1 * 2);
-      unsigned own2 = 0;
+      d.own[i] = (unsigned)((pl + p.HW) * C1 * 2);
+      d.own2[i] = 0;
       if (DUAL) {
         const int rem = (ok ? m : m0) - n * p.HW;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        own2 = (unsigned)((n - n0) * frame2_bytes + ((oy * p.stride2) * p.Wi2 + ox * p.stride2) * C2 * 2);
+        d.own2[i] = (unsigned)((n - n0) * frame2_bytes + ((oy * p.stride2) * p.Wi2 + ox * p.stride2) * C2 * 2);
       }
-#pragma unroll
-      for (int k = 0; k < PPW; ++k) {
-        const int g = PPW * wave + k;
-        const int c0 = (2 * g + hsel) * 8;
-        lds_void *dst = (lds_void *)(lds + b * kBuf + g * kPlane + i * 1024);
-        if (DUAL && c0 >= C1) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX2, dst, 16, (int)(ok ? own2 + (unsigned)((c0 - C1) * 2) : kInvalid), 0, 0, 0);
-        } else {
-          unsigned off = own;
-          bool valid = ok;
-          if (p.T > 0 && c0 < p.fold) { off = own + (unsigned)frame_bytes; valid = ok && tt < p.T - 1; }
-          else if (p.T > 0 && c0 < 2 * p.fold) { off = own - (unsigned)frame_bytes; valid = ok && tt > 0; }
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, dst, 16, (int)(valid ? off + (unsigned)(c0 * 2) : kInvalid), 0, 0, 0);
-        }
-      }
+      d.vmask[i] = (ok ? 1u : 0u) | ((ok && tt < p.T - 1) ? 2u : 0u) | ((ok && tt > 0) ? 4u : 0u);
+    }
+    return d;
+  };
+  auto piece = [&](const TileDma &d, int b, int i, int k) {
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(d.px), 0, d.szx, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(d.px2), 0, d.szx2, 0x00020000);
+    const int g = PPW * wave + k;
+    const int c0 = (2 * g + hsel) * 8;
+    lds_void *dst = (lds_void *)(lds + b * kBuf + g * kPlane + i * 1024);
+    const bool ok = (d.vmask[i] & 1u) != 0;
+    if (DUAL && c0 >= C1) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX2, dst, 16, (int)(ok ? d.own2[i] + (unsigned)((c0 - C1) * 2) : kInvalid), 0, 0, 0);
+    } else {
+      unsigned off = d.own[i];
+      bool valid = ok;
+      if (p.T > 0 && c0 < p.fold) { off = d.own[i] + (unsigned)frame_bytes; valid = (d.vmask[i] & 2u) != 0; }
+      else if (p.T > 0 && c0 < 2 * p.fold) { off = d.own[i] - (unsigned)frame_bytes; valid = (d.vmask[i] & 4u) != 0; }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, dst, 16, (int)(valid ? off + (unsigned)(c0 * 2) : kInvalid), 0, 0, 0);
     }
   };
+  constexpr int kPieces = MT * PPW, kEvery = NG / PPW;   // one piece per kEvery (= 4) MFMA steps: the last one behind step MT * NG - kEvery
+  static_assert(kEvery * PPW == NG && kPieces * kEvery == MT * NG, "the pieces spread evenly over the tile's MFMA steps");
 
   const size_t ybytes = (size_t)p.M * CTOT * 2;
   int t = tfirst, nb = 0;
-  if (t < ntiles) issue_tile(p.reverse ? ntiles - 1 - t : t, 0);
+  if (t < ntiles) {
+    const TileDma d0 = prep(p.reverse ? ntiles - 1 - t : t, true);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int k = 0; k < PPW; ++k) piece(d0, 0, i, k);
+  }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   for (; t < ntiles; t += tstep, nb ^= 1) {
     __builtin_amdgcn_s_barrier();
     const int tn = t + tstep;
-    if (tn < ntiles) issue_tile(p.reverse ? ntiles - 1 - tn : tn, nb ^ 1);
+    const int tnn = tn < ntiles ? tn : t;                                // (no next tile: dead pieces, zeros, no memory traffic)
+    const TileDma dn = prep(p.reverse ? ntiles - 1 - tnn : tnn, tn < ntiles);
     const int tt = p.reverse ? ntiles - 1 - t : t;
     const unsigned char *buf = lds + nb * kBuf;
     // output window of the tile (rebased: 32-bit offsets whatever M * COUT is)
@@ -1130,6 +1150,10 @@ __global__ void __launch_bounds__(256, 1) conv1x1_wsn_kernel(const WsnParams p) 
         for (int nt = 0; nt < NTW; ++nt)
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wr[nt][g]), __builtin_bit_cast(bf16x8, px),
                                                             acc[nt], 0, 0, 0);
+        if ((mt * NG + g) % kEvery == kEvery - 1) {                      // the next tile's piece (mt * NG + g) / kEvery, behind this step's MFMAs
+          const int j = (mt * NG + g) / kEvery;
+          piece(dn, nb ^ 1, j / PPW, j % PPW);
+        }
       }
       const unsigned yoff = (unsigned)(pp * CTOT * 2 + nh * COUT * 2);   // (rows past M fall outside the rebased window)
 #pragma unroll
@@ -1157,7 +1181,7 @@ __global__ void __launch_bounds__(256, 1) conv1x1_wsn_kernel(const WsnParams p) 
         }
       }
     }
-    wait_vmcnt(MT * NTW * 2);   // the next tile is older than this tile's stores
+    wait_vmcnt(NTW * 2);        // the next tile's last piece is older than the last M-tile's stores (and younger than every other store)
   }
 }
 
