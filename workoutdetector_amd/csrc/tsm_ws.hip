@@ -590,6 +590,44 @@ static int ws128_best_swap(bool s2, int TR, int TC) {
   return best;
 }
 
+// The stride-1 tile of a frame: fewest tiles first (ws_tile_geometry's rule), and among the shapes with that many tiles the one whose
+// fragment reads cost the fewest LDS cycles under its best swap -- the shapes differ by a factor of two there: on 32 x 32 frames
+// 16 x 8 and 8 x 16 both give 8 tiles, but an M-tile of four 8-pixel rows puts FOUR lanes of a 16-lane read group on one pair of
+// 16-byte slots (two entries per slot pair: 2-way conflicts whatever the swap, 50 % of the LDS cycles), while two 16-pixel rows
+// with the halves swapped on the row's parity read conflict-free.
+static bool ws128_tile_geometry(int H, int W, int *tr_out, int *tc_out, int *swz_out) {
+  // (a pure function of the frame size, but ~10^7 operations of modelling: every launch of an engine asks for the same one or
+  //  two sizes, so the calling thread remembers its last four answers)
+  struct Memo { int H, W, tr, tc, swz; bool ok; };
+  static thread_local Memo memo[4] = {};
+  static thread_local int memo_next = 0;
+  for (const Memo &m : memo)
+    if (m.H == H && m.W == W && m.H > 0) {
+      *tr_out = m.tr; *tc_out = m.tc;
+      if (swz_out) *swz_out = m.swz;
+      return m.ok;
+    }
+  long best_tiles = -1;
+  int best_tr = 0, best_tc = 0, best_cycles = 0, best_swz = 0;
+  for (int tc = 4; tc <= 128; ++tc) {
+    int tr = 128 / tc;
+    if (tr > H) tr = H;
+    if (tr < 1 || (tr + 2) * (tc + 2) > kW8PatchMax) continue;
+    const long tiles = (long)((H + tr - 1) / tr) * ((W + tc - 1) / tc);
+    if (best_tiles >= 0 && tiles > best_tiles) continue;
+    const int swz = ws128_best_swap(false, tr, tc), cycles = ws128_read_cycles(false, tr, tc, swz);
+    if (best_tiles < 0 || tiles < best_tiles || cycles < best_cycles) {
+      best_tiles = tiles; best_tr = tr; best_tc = tc; best_cycles = cycles; best_swz = swz;
+    }
+  }
+  *tr_out = best_tr;
+  *tc_out = best_tc;
+  if (swz_out) *swz_out = best_swz;
+  memo[memo_next] = Memo{H, W, best_tr, best_tc, best_swz, best_tiles > 0};
+  memo_next = (memo_next + 1) & 3;
+  return best_tiles > 0;
+}
+
 template <bool S2>
 __global__ void __launch_bounds__(256, 1) conv3x3_ws128_kernel(const WsParams p) {
   constexpr int kRounds = S2 ? kS2Rounds : kW8Rounds, kPlane = S2 ? kS2Plane : kW8Plane, kBuf = 8 * kPlane;
@@ -852,7 +890,7 @@ static bool conv3x3_ws128s2_valid(const ConvParams &p) {
 bool conv3x3_ws128_valid(const ConvParams &p) {
   int tr, tc;
   if (conv3x3_ws128s2_valid(p)) return true;
-  return conv3x3_ws128_common(p) && p.stride == 1 && p.Hi == p.Ho && p.Wi == p.Wo && ws_tile_geometry(p.Hi, p.Wi, &tr, &tc, 128, kW8PatchMax);
+  return conv3x3_ws128_common(p) && p.stride == 1 && p.Hi == p.Ho && p.Wi == p.Wo && ws128_tile_geometry(p.Hi, p.Wi, &tr, &tc, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1214,7 +1252,11 @@ hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
     q.x = p.x; q.w2 = p.w; q.bias2 = p.bias; q.y = p.y;
     q.N = p.N; q.H = p.Hi; q.W = p.Wi; q.M = p.M; q.relu = p.relu; q.reverse = p.reverse;
     ws_s2_tile_geometry(p.Ho, p.Wo, &q.tr, &q.tc);
-    q.swz = ws128_best_swap(true, q.tr, q.tc);
+    {
+      static thread_local int m_tr = 0, m_tc = 0, m_swz = 0;       // (the same modelling cost: remembered per thread)
+      if (m_tr != q.tr || m_tc != q.tc) { m_swz = ws128_best_swap(true, q.tr, q.tc); m_tr = q.tr; m_tc = q.tc; }
+      q.swz = m_swz;
+    }
     const long ntiles = (long)q.N * ((p.Ho + q.tr - 1) / q.tr) * ((p.Wo + q.tc - 1) / q.tc);
     const int n_cu = ws_grid_setup();
     if (device_info().status != hipSuccess) return device_info().status;
@@ -1225,8 +1267,7 @@ hipError_t launch_conv3x3_ws(ConvParams p, hipStream_t s) {
     WsParams q{};
     q.x = p.x; q.w2 = p.w; q.bias2 = p.bias; q.y = p.y;
     q.N = p.N; q.H = p.Hi; q.W = p.Wi; q.M = p.M; q.relu = p.relu; q.reverse = p.reverse;
-    ws_tile_geometry(q.H, q.W, &q.tr, &q.tc, 128, kW8PatchMax);
-    q.swz = ws128_best_swap(false, q.tr, q.tc);
+    ws128_tile_geometry(q.H, q.W, &q.tr, &q.tc, &q.swz);
     const long ntiles = (long)q.N * ((q.H + q.tr - 1) / q.tr) * ((q.W + q.tc - 1) / q.tc);
     const int n_cu = ws_grid_setup();
     if (device_info().status != hipSuccess) return device_info().status;
