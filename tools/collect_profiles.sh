@@ -6,7 +6,9 @@ for m in f32 bf16c5 bf16x3; do
   cp $G/${t}_${m}_kernel_stats.csv $P/${t}_${m}_kernel_stats.csv
   cp $G/${t}_${m}_per_layer.txt $P/${t}_${m}_per_layer.txt
   cp $G/${t}_${m}_hbm_traffic.txt $P/${t}_${m}_hbm_traffic.txt
+  [ -f $G/${t}_${m}_traffic_per_launch.txt ] && cp $G/${t}_${m}_traffic_per_launch.txt $P/${t}_${m}_traffic_per_launch.txt
 done
+[ -f $G/${t}_bf16c5_pmc_insts.txt ] && cp $G/${t}_bf16c5_pmc_insts.txt $P/
 cp $G/${t}_f32_pmc_sq.txt $G/${t}_bf16c5_pmc_sq1.txt $G/${t}_bf16c5_pmc_sq2.txt $G/${t}_bf16x3_pmc_sq.txt $P/
 cp $G/${t}_f32_bench_line.json $P/${t}_f32_b32_bench_line_profiled.json
 cp $G/${t}_bf16c5_bench_line.json $P/${t}_bf16_config5_bench_line_profiled.json
