@@ -77,7 +77,7 @@ static void fuzz_tune_lines(unsigned seed, int rounds) {
     if (line.size() > 4000) line.resize(4000);
     std::vector<int> codes(5, -7);
     const bool ok = parse_tune_line(line.c_str(), want, kNumTiles, &codes);
-    for (int c : codes) EXPECT(ok ? (c >= 0 && (c & ~0x1D0F) == 0 && (c & 15) < kNumTiles) : c == -7);
+    for (int c : codes) EXPECT(ok ? (c >= 0 && (c & ~0x3F0F) == 0 && (c & 15) < kNumTiles) : c == -7);
   }
 }
 
@@ -162,7 +162,37 @@ static void check_packing(unsigned seed) {
   EXPECT(tile_bucket(1) == 1 && tile_bucket(5) == 8 && tile_bucket(32) == 32 && tile_bucket(33) == 64);
 }
 
+// tail_split_point: where a segmented 64x64 launch is cut into whole-K tiles and (tile, K segment) pieces.
+static void check_tail_split() {
+  using tsm_host::tail_split_point;
+  const size_t big = (size_t)16 << 20;
+  // headline shape, 256 CUs (rounds of 1 280 tiles): layer3 3x3 (M = 50 176, Cout 256: 3 136 tiles = 2.45 rounds), layer4 3x3
+  // (M = 12 544, Cout 512: 1 568 = 1.225 rounds)
+  EXPECT(tail_split_point(50176, 256, 4, 256, big) == 2560);
+  EXPECT(tail_split_point(12544, 512, 9, 256, big) == 1280);
+  // the result is a multiple of ntn, inside (0, tiles), and the scratch holds the tail's segment sums -- for every shape
+  std::mt19937 rng(7);
+  for (int r = 0; r < 20000; ++r) {
+    const long m = 1 + (long)(rng() % 400000);
+    const int cout = 64 * (1 + (int)(rng() % 32)), nseg = 1 + (int)(rng() % 12), ncu = 1 + (int)(rng() % 320);
+    const size_t scratch = (size_t)(rng() % (32u << 20));
+    const long from = tail_split_point(m, cout, nseg, ncu, scratch);
+    const long ntn = cout / 64, tiles = (m + 63) / 64 * ntn, slots = 5L * ncu;
+    if (from == 0) continue;
+    EXPECT(nseg >= 2 && from > 0 && from < tiles && from % ntn == 0 && from % 1 == 0);
+    EXPECT(from <= tiles / slots * slots && tiles / slots >= 1);                       // only whole rounds stay whole-K
+    EXPECT((tiles - tiles / slots * slots) * 100 <= slots * 85);                      // a nearly full last round is left alone
+    EXPECT((size_t)nseg * (size_t)(m - from / ntn * 64) * (size_t)cout <= scratch);   // the segment sums of the tail rows fit
+  }
+  EXPECT(tail_split_point(50176, 256, 4, 256, 1000) == 0);          // scratch too small
+  EXPECT(tail_split_point(5488, 512, 9, 256, big) == 0);            // 688 tiles: no whole round
+  EXPECT(tail_split_point(81920, 256, 4, 256, big) == 0);           // 5 120 tiles: exactly four rounds
+  EXPECT(tail_split_point(50176, 256, 1, 256, big) == 0);           // one segment: nothing to split
+  EXPECT(tail_split_point(50176, 96, 4, 256, big) == 0 && tail_split_point(0, 256, 4, 256, big) == 0 && tail_split_point(50176, 256, 4, 0, big) == 0);
+}
+
 int main(int argc, char **argv) {
+  check_tail_split();
   const int rounds = argc > 1 ? std::atoi(argv[1]) : 20000;
   fuzz_tune_lines(1234, rounds);
   check_packing(99);

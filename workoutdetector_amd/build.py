@@ -10,6 +10,7 @@ from __future__ import annotations
 import os
 import shutil
 import subprocess
+import tempfile
 import sys
 from typing import List
 
@@ -112,9 +113,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB_PATH
     defs = build_defs()
-    # A/B builds (TSM_LIB_PATH / TSM_BUILD_DEFS) keep their objects apart from the product's
+    # A/B builds (TSM_LIB_PATH / TSM_BUILD_DEFS) keep their objects apart from the product's -- and out of the tree (a dozen
+    # variants are 30 MB of objects that would travel with every snapshot of the repository)
     tag = '' if not (defs or os.environ.get('TSM_LIB_PATH')) else '_' + hashlib_tag(' '.join(defs) + LIB_PATH)
-    obj_dir = OBJ_DIR + tag
+    obj_dir = OBJ_DIR if not tag else os.path.join(tempfile.gettempdir(), 'tsm_hip_obj' + tag)
     os.makedirs(obj_dir, exist_ok=True)
     newest_header = max(os.path.getmtime(h) for h in _headers())
     base = [_hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC'] + defs + ['-I', INCLUDE]

@@ -72,6 +72,25 @@ template <int CIN> struct BnLds {
 // 2s - 1 (M-tiles 0, 1) was the second row of the PREVIOUS step's input: holding it for a step takes 32 registers the file
 // does not have (built: 512 registers and 20 spills), so it still comes from memory.  With the temporal shift the first 64
 // channels of a slot come from frames t +- 1, so the wave that owns output channels 0-63 keeps loading all of its identity.
+#ifndef TSM_BNECK_PXR64
+#define TSM_BNECK_PXR64 4   // conv2's fragment ring of the 64-channel form (8 = reads seven steps ahead instead of three: measured, no change)
+#endif
+#ifndef TSM_BNECK_X
+#define TSM_BNECK_X 0       // timing probes (garbage results): 1 the output stores fully coalesced (1 KB contiguous per instruction),
+#endif                      // 2 the identity loads of the 64-channel form likewise
+#ifndef TSM_BNECK_STAMP
+#define TSM_BNECK_STAMP 0   // diagnostic builds only: per-phase cycle sums of workgroup 0's four waves (s_memtime), printed at the kernel's end
+#endif
+#if TSM_BNECK_STAMP
+#define BN_STAMP(i)                                         \
+  do {                                                      \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+    stamp_acc[i] += _t - stamp_last;                        \
+    stamp_last = _t;                                        \
+  } while (0)
+#else
+#define BN_STAMP(i) do {} while (0)
+#endif
 template <int CIN, bool SHIFT, bool IDL = false>
 __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
   constexpr bool DUAL = CIN == 64;
@@ -207,6 +226,9 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                         // biases and the zeroed line buffer are in place
 
+#if TSM_BNECK_STAMP
+  unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
   for (; fi < p.N; fi += gridDim.x) {
     const int f = frame_of(fi);
     const int fnext = fi + (int)gridDim.x < p.N ? frame_of(fi + (int)gridDim.x) : -1;
@@ -222,8 +244,10 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
     for (int s = 0; s < nsteps; ++s) {
       const int r0 = 2 * s - 1;                                         // output rows r0, r0 + 1; conv1 rows 2s, 2s + 1
       // ================= conv1: rows 2s, 2s + 1 -> line buffer =================
+      BN_STAMP(6);
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                 // this step's input has landed (the 16 youngest operations are the previous step's stores)
       if constexpr (IDL) __builtin_amdgcn_s_barrier();                  // ... every wave's: the identity below is read from all four slots
+      BN_STAMP(0);
       // The identity operand of this step's four M-tiles, 4 x 16 bytes per lane and M-tile:
       //   CIN 256  res[mt][2 itl + qq] = bytes [64 it + 16 (2 half + qq), + 16) of the pixel's 512 (the store layout);
       //   CIN 64   res[mt][g] = channels 16 g + 8 half .. + 8 of the pixel: the B fragment of k16 group g.
@@ -258,10 +282,17 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
         // ("+v") in front of their first consumer; the ISA is audited for moves of them (tests/test_code_objects.py).
         asm volatile("s_nop 4" ::: "memory");            // (the descriptor may be fresh from scalar moves: nothing inside asm is padded)
         if constexpr (DUAL) {
+#if TSM_BNECK_X & 2
+          const unsigned o = (unsigned)((s * 16 + mt * 4) * 1024 + lane * 16);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(res[mt][g]) : "v"(o), "s"(rsrcR), "n"(g * 1024) : "memory");
+#else
           const unsigned o = ok ? (unsigned)((r * W + c) * XROW + half * 16) : kInvalid;
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(res[mt][g]) : "v"(o), "s"(rsrcR), "n"(g * 32) : "memory");
+#endif
         } else {
           const unsigned o = ok ? (unsigned)((r * W + c) * 512 + (2 * wave) * 64 + 2 * half * 16) : kInvalid;
 #pragma unroll
@@ -339,7 +370,9 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      BN_STAMP(1);
       __builtin_amdgcn_s_barrier();    // rows 2s - 2 .. 2s + 1 are complete; nobody still reads the mid tile of the previous step
+      BN_STAMP(2);
       // IDL: ... nor anybody's input slot: re-arm it (a step minus the conv1 phase ahead), piece by piece behind conv2's MFMAs
       // (round 5; behind the late identity loads in the wave's issue order)
       XDma xd{};
@@ -361,7 +394,9 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
-        u32x4 px[4][2];
+        // fragment reads run PXR - 1 steps ahead of their MFMA (3; the 64-channel form has registers for a ring of eight: no change)
+        constexpr int PXR = TSM_BNECK_PXR64 > 4 && CIN == 64 ? TSM_BNECK_PXR64 : 4;
+        u32x4 px[PXR][2];
         unsigned tb[2] = {0u, 0u};
         auto rd = [&](int st) {
           const int tap = st >> 2, g = st & 3, ky = tap / 3, kx = tap - ky * 3;
@@ -371,16 +406,18 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
               const int pp = ((2 * s + drr[m] + ky) & 3) * kBnRP + cc[m] + kx;      // row r0 + dr - 1 + ky, column c - 1 + kx (+ 1)
               tb[m] = (unsigned)(pp * 32 + ((half ^ ((pp >> 3) & 1)) << 4));
             }
-            px[st & 3][m] = *reinterpret_cast<const u32x4 *>(lds + tb[m] + g * kBnT1Plane);
+            px[st & (PXR - 1)][m] = *reinterpret_cast<const u32x4 *>(lds + tb[m] + g * kBnT1Plane);
           }
         };
-        rd(0); rd(1); rd(2);
+        BN_STAMP(7);      // (conv2's prologue: the late identity loads, lane geometry, accumulators)
+#pragma unroll
+        for (int st = 0; st < PXR - 1; ++st) rd(st);
         static_for<36>([&](auto sc) __attribute__((always_inline)) {
           constexpr int st = decltype(sc)::value;
-          if constexpr (st + 3 < 36) rd(st + 3);
+          if constexpr (st + PXR - 1 < 36) rd(st + PXR - 1);
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w2r[st]), __builtin_bit_cast(bf16x8, px[st & 3][m]),
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w2r[st]), __builtin_bit_cast(bf16x8, px[st & (PXR - 1)][m]),
                                                              acc[m], 0, 0, 0);
             if constexpr (IDL && st >= 2 && st < 2 + 2 * NDMA && (st & 1) == 0) {
               if (m == 0) x_piece(xd, std::integral_constant<int, (st - 2) / 2>{});      // one piece every second step, behind an MFMA
@@ -388,6 +425,7 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
           }
           __builtin_amdgcn_sched_barrier(0);
         });
+        BN_STAMP(8);      // (conv2's 36 steps)
         // bias2, ReLU, bf16 -> the mid tile, in conv3's B-fragment order (plane g' = 2 nt2 + qq)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -409,7 +447,9 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      BN_STAMP(3);
       __builtin_amdgcn_s_barrier();    // the mid tile is complete; the line buffer may be overwritten by the next step
+      BN_STAMP(4);
       // ================= conv3 + identity: all four M-tiles, output channels 64 wave .. + 64 =================
       u32x4 w3r[2][NG3];
 #pragma unroll
@@ -435,7 +475,11 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
           for (int itl = 0; itl < 2; ++itl)
             c3[itl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w3r[itl][g]), __builtin_bit_cast(bf16x8, bf[g]), c3[itl], 0, 0, 0);
         const int dr = ml >= W ? 1 : 0, c = ml - dr * W, r = r0 + dr;
+#if TSM_BNECK_X & 1
+        const unsigned yo = (unsigned)(((s * 4 + wave) * 16 + mt * 4) * 1024 + lane * 16 - (l31 * 0));   // (+ itl * 64 + qq * 16 below: patched to * 1024 there)
+#else
         const unsigned yo = (ml < W2 && (unsigned)r < (unsigned)H) ? (unsigned)((r * W + c) * 512 + (2 * wave) * 64 + 2 * half * 16) : kInvalid;
+#endif
         // this M-tile's identity operand; younger operations: M-tiles 0, 1 -- the other early loads (4 / 0), the next input
         // (NDMA), the late loads (8), the stores so far (0 / 4) = NDMA + 12; M-tiles 2, 3 -- the other late loads and the
         // stores so far = 12
@@ -499,12 +543,22 @@ __global__ void __launch_bounds__(256, 1) bneck_ws_kernel(const BneckParams p) {
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq) {
             const u32x4 o = {pk[qq][0], pk[qq][1], pk[qq + 2][0], pk[qq + 2][1]};
+#if TSM_BNECK_X & 1
+            __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)yo, (itl * 2 + qq) * 1024, TSM_AUX_BNECK);
+#else
             __builtin_amdgcn_raw_buffer_store_b128(o, rsrcY, (int)yo, itl * 64 + qq * 16, TSM_AUX_BNECK);
+#endif
           }
         }
       });
+      BN_STAMP(5);
     }
   }
+#if TSM_BNECK_STAMP
+  if (blockIdx.x == 0 && lane == 0)
+    printf("bneck<%d,%d,%d> wave %d: input wait %llu conv1 %llu barrier1 %llu conv2 %llu (prologue %llu steps %llu epilogue %llu) barrier2 %llu conv3 %llu between steps %llu cycles\n", CIN, (int)SHIFT,
+           (int)IDL, wave, stamp_acc[0], stamp_acc[1], stamp_acc[2], stamp_acc[3] + stamp_acc[7] + stamp_acc[8], stamp_acc[7], stamp_acc[8], stamp_acc[3], stamp_acc[4], stamp_acc[5], stamp_acc[6]);
+#endif
 }
 
 bool bneck_ws_valid(int cin, int n, int h, int w, int T, int fold) {

@@ -282,21 +282,12 @@ void tune_cache_store(tsm_engine *e, int key, const std::vector<int> &codes) {
   fclose(f);
 }
 
-// The tail split of a segmented 64x64 launch (ConvParams::ksplit = 2, tile code bit 0x200): the conv_igemm SEG kernel keeps five
-// workgroups per CU resident, so a launch runs in rounds of 5 * n_cu tiles; when the last round is less than ~85 % full, its
-// tiles -- rounded to whole rows of tiles -- run as (tile, K segment) pieces.  False when there is no whole round, no
-// remainder worth splitting, or the segment sums do not fit the scratch buffer.
+// The tail split of a segmented 64x64 launch (tile code bit 0x200): tsm_host_util.h::tail_split_point on this launch's shape.
 bool tail_split_from(const tsm::ConvParams &p, int n_cu, size_t partial_elems, int *tail_from) {
-  if (p.kseg_len <= 0 || p.Cout % 64 != 0 || n_cu <= 0) return false;
-  const long ntn = p.Cout / 64, ntm = ((long)p.M + 63) / 64, tiles = ntm * ntn, slots = 5L * n_cu;
-  const long rounds = tiles / slots, rem = tiles - rounds * slots;
-  if (rounds < 1 || rem == 0 || rem * 100 > slots * 85) return false;
-  const long from = rounds * slots / ntn * ntn;            // whole rows of tiles
-  if (from <= 0 || from >= tiles) return false;
-  const size_t tail_rows = (size_t)p.M - (size_t)(from / ntn) * 64;
-  if ((size_t)tsm::conv_num_segments(p) * tail_rows * (size_t)p.Cout > partial_elems) return false;
+  if (p.kseg_len <= 0) return false;
+  const long from = tsm_host::tail_split_point(p.M, p.Cout, tsm::conv_num_segments(p), n_cu, partial_elems);
   *tail_from = (int)from;
-  return true;
+  return from > 0;
 }
 
 struct Tap {
@@ -1241,6 +1232,17 @@ int tsm_conv_tiles(tsm_engine *e, int32_t n_clips, int32_t *tiles_out, int32_t c
   if ((int)order.size() > cap) return fail(e, TSM_ERR_CAPACITY, "tiles_out too small");
   auto it = e->tile_cache.find(tile_bucket(n_clips) * e->cfg.num_segments);
   for (size_t i = 0; i < order.size(); ++i) tiles_out[i] = it == e->tile_cache.end() ? 0 : it->second[order[i]];
+  // Report what RUNS: a block whose conv2 carries 0x400 (conv2 + conv3 fused) or whose conv1 carries 0x800 (the whole block)
+  // never reaches the conv3 + next-conv1 launch, whatever bit 0x1000 of its conv3 code says (a forced or hand-edited code; the
+  // tuner itself times 0x1000 only on blocks that run conv3 as a launch of its own)  (ADVICE r4).
+  if (it != e->tile_cache.end()) {
+    size_t i = 1;
+    for (const Block &b : e->blocks) {
+      if (b.down >= 0) ++i;
+      if ((tiles_out[i] & 0x800) || (tiles_out[i + 1] & 0x400)) tiles_out[i + 2] &= ~0x1000;
+      i += 3;
+    }
+  }
   return TSM_OK;
 }
 

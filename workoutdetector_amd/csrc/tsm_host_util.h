@@ -4,6 +4,7 @@
 // not available on this pool).
 #pragma once
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,24 @@ inline int segment_len(int kp, int prec) {
 }
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// The tail split of a segmented 64x64 launch (ConvParams::ksplit = 2, tile code bit 0x200).  The conv_igemm SEG kernel keeps
+// `wg_per_cu` (five) workgroups per CU resident, so a launch of ntm x ntn tiles runs in rounds of wg_per_cu * n_cu; when the last
+// round is less than ~85 % full its tiles -- rounded DOWN to whole rows of tiles, so that the tail is a contiguous range of output
+// rows -- run as (tile, K segment) pieces.  Returns the first tail tile (a multiple of ntn, in (0, ntm * ntn)), or 0 when the
+// launch should stay whole-K: no whole round, no remainder worth splitting, or the segment sums [n_seg][tail rows][cout] do not
+// fit `scratch_elems` floats.
+inline long tail_split_point(long m_rows, int cout, int n_seg, int n_cu, size_t scratch_elems, int wg_per_cu = 5) {
+  if (m_rows <= 0 || cout <= 0 || cout % 64 != 0 || n_seg < 2 || n_cu <= 0) return 0;
+  const long ntn = cout / 64, ntm = (m_rows + 63) / 64, tiles = ntm * ntn, slots = (long)wg_per_cu * n_cu;
+  const long rounds = tiles / slots, rem = tiles - rounds * slots;
+  if (rounds < 1 || rem == 0 || rem * 100 > slots * 85) return 0;
+  const long from = rounds * slots / ntn * ntn;
+  if (from <= 0 || from >= tiles) return 0;
+  const size_t tail_rows = (size_t)(m_rows - (from / ntn) * 64);
+  if ((size_t)n_seg * tail_rows * (size_t)cout > scratch_elems) return 0;
+  return from;
+}
 
 inline uint16_t f2bf(float f) {  // round to nearest even, like v_cvt_pk_bf16_f32
   uint32_t u;
