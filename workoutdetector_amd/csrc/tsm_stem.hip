@@ -178,9 +178,25 @@ constexpr int kPoolPR = 2 * kPoolCR + 5, kPoolPC = kPoolCC + 3;      // input pa
 // pack_input_kernel would have written: a patch chunk is then six floats (two pixels x three colour planes) that are held
 // raw while the previous tile computes and rounded / split exactly as pack_input does (store_group's arithmetic) when the
 // patch is written to LDS -- same bits, and the forward loses the pack launch with its write and re-read of the packed tensor.
+#ifndef TSM_STEM_WREG
+#define TSM_STEM_WREG 4
+#endif
+#ifndef TSM_STEM_STAMP
+#define TSM_STEM_STAMP 0   // diagnostic builds only: per-phase cycle sums of workgroup 0 (s_memtime), printed at the kernel's end
+#endif
+#if TSM_STEM_STAMP
+#define ST_STAMP(i)                                         \
+  do {                                                      \
+    const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+    stamp_acc[i] += _t - stamp_last;                        \
+    stamp_last = _t;                                        \
+  } while (0)
+#else
+#define ST_STAMP(i) do {} while (0)
+#endif
 template <bool X3, bool PLANAR>
 // (bf16: 77 760 B of LDS and <= 128 registers, so that TWO workgroups share a CU and overlap each other's phases)
-__global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float *__restrict__ x, const float *__restrict__ w,
+__global__ void __launch_bounds__(512, X3 ? 1 : 4) stem_pool_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ bias, float *__restrict__ y, int n,
                                                         int hi, int wi, int ho, int wo, int hp, int wp, int kp, int relu) {
   constexpr int NT = 512;
@@ -296,7 +312,21 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
     }
   };
   // (tiles in XCD-chunked order: horizontally and vertically neighbouring tiles share up to half of their patch lines)
+#if TSM_STEM_STAMP
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
   if ((int)blockIdx.x < n_tiles) fetch_patch((int)xcd_chunked(blockIdx.x, n_tiles));
+  // bf16: the weight fragments of this lane's second channel tile (14 x 16 bytes) live in registers for the life of the workgroup
+  // -- the kernel used 56 of the 128 registers two workgroups per CU leave it, and every wave read the same 28 fragments from
+  // LDS for every tile: one LDS read in three of the MFMA phase is gone (TSM_STEM_WREG)
+  constexpr int NWREG = X3 ? 0 : TSM_STEM_WREG;     // fragments held (the first NWREG k16 steps)
+  constexpr bool kWreg = NWREG > 0;
+  u32x4 wreg[kWreg ? NWREG : 1];
+  if constexpr (kWreg) {
+    __syncthreads();      // (the weights are in LDS)
+#pragma unroll
+    for (int s16 = 0; s16 < NWREG; ++s16) wreg[s16] = *reinterpret_cast<const u32x4 *>(b_base + (2 * s16 + half) * GB + 32 * WROW);
+  }
   for (int v = blockIdx.x; v < n_tiles; v += gridDim.x) {
     const int t = (int)xcd_chunked(v, n_tiles);
     const int f = t / tiles_f, rem = t - f * tiles_f, ty = rem / tiles_x, tx = rem - ty * tiles_x;
@@ -304,12 +334,16 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
     const int oy0 = 2 * py0 - 1, ox0 = 2 * px0 - 1;   // conv pixel of tile position (0, 0)
     const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char *>(y) + (size_t)f * y_frame, 0, (int)y_frame, 0x00020000);
+    ST_STAMP(5);
     __syncthreads();
+    ST_STAMP(0);
 #pragma unroll
     for (int q = 0; q < PPASS; ++q)
       if (tid + q * NT < PCH) *reinterpret_cast<u32x4 *>(Ps + patch_slot(tid + q * NT)) = packed_chunk(q);
     if (v + (int)gridDim.x < n_tiles) fetch_patch((int)xcd_chunked(v + gridDim.x, n_tiles));
+    ST_STAMP(1);
     __syncthreads();
+    ST_STAMP(2);
     f32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -322,7 +356,7 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
       const unsigned char *bp = b_base + g * GB;
       const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap));
       const bf16x8 bh0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp));
-      const bf16x8 bh1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 32 * WROW));
+      const bf16x8 bh1 = __builtin_bit_cast(bf16x8, (kWreg && s16 < NWREG) ? wreg[(kWreg && s16 < NWREG) ? s16 : 0] : *reinterpret_cast<const u32x4 *>(bp + 32 * WROW));
       if constexpr (X3) {
         const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ap + 16));
         const bf16x8 bl0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bp + 16));
@@ -376,7 +410,9 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
           *reinterpret_cast<u32x2 *>(Cs16 + mi * 72 + j * 32 + 8 * q + 4 * half) = inside ? o : ninf;
         }
     }
+    ST_STAMP(3);
     __syncthreads();
+    ST_STAMP(4);
     if (tid < kPoolPH * kPoolPW * 8) {  // one 8-channel group of one pooled pixel per thread
       const int pp = tid >> 3, cg = tid & 7;
       const int pyl = pp / kPoolPW, pxl = pp - pyl * kPoolPW;
@@ -444,6 +480,11 @@ __global__ void __launch_bounds__(512, X3 ? 1 : 2) stem_pool_kernel(const float 
       }
     }
   }
+#if TSM_STEM_STAMP
+  if (blockIdx.x == 0 && (tid == 0 || tid == 448))
+    printf("stem<%d,%d> wave %d: barrier1 %llu stage patch %llu barrier2 %llu mfma + tile epilogue %llu barrier3 %llu pool + store %llu cycles\n", (int)X3, (int)PLANAR,
+           tid >> 6, stamp_acc[0], stamp_acc[1], stamp_acc[2], stamp_acc[3], stamp_acc[4], stamp_acc[5]);
+#endif
 }
 
 // fp32 form of stem_pool.  Input NHWC4 (one 16-byte group per pixel), weights [64][Kp] fp32 with K = (ky, kx, c4);
