@@ -322,6 +322,68 @@ def test_profiling_tools_find_the_forwards_with_and_without_a_pack_launch():
     assert labels[0] == 'conv1' and labels[1] == 'layer1.0 (block)' and labels[4] == 'layer2.0.conv1'
     assert 'layer2.1.conv3+layer2.2.conv1' in labels and 'layer2.3.conv3+layer3.0.conv1' in labels and 'layer3.4.conv3+layer3.5.conv1' in labels
     assert labels[-1] == 'layer4.2.conv3' and 'layer3.0.conv1' not in labels and 'layer3.1.conv1' in labels
+    # round 5's schedule: layer2.0's conv1 + stride-2 conv2 as one launch, its conv3 + downsample on workgroup pairs, the
+    # producer / consumer form of conv3 + next conv1
+    names5 = list(names)
+    names5[4:7] = ['front_s2_kernel<true>', 'conv1x1_wsn_kernel<384, 256, true, 2>']
+    names5 = [n.replace('conv31_fused_kernel<128, 512, 256, 2>', 'conv31_pc_kernel<128, 512, 256>')
+               .replace('conv31_fused_kernel<256, 1024, 256, 2>', 'conv31_pc_kernel<256, 1024, 256>') for n in names5]
+    rows5, ok5 = match_schedule([dict(Kernel_Name='void tsm::' + n + '(tsm::ConvParams)') for n in names5])
+    assert ok5 and len(rows5) == len(names5) == len(names) - 1
+    labels5 = [r[0] for r in rows5]
+    assert labels5[4] == 'layer2.0.conv1+conv2' and rows5[4][1] == ['layer2.0.conv1', 'layer2.0.conv2']
+    assert labels5[5] == 'layer2.0.conv3+downsample' and 'layer3.4.conv3+layer3.5.conv1' in labels5 and labels5[-1] == 'layer4.2.conv3'
+
+
+def test_per_launch_roofline_columns_of_the_traffic_table(tmp_path, capsys):
+    """tools/traffic_per_launch.py: with a kernel trace of the same schedule every launch gets us / bound_us / x_bound / roof --
+    bound = max(algorithmic bytes / 8 TB/s, algorithmic flops / the mode's dense MFMA peak).  A two-launch synthetic forward
+    (the stem and a whole layer1.0 block) is priced by hand here."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    try:
+        import traffic_per_launch as tpl
+    finally:
+        sys.path.pop(0)
+    kernels = ['void tsm::stem_pool_kernel<false, true>(float const*)', 'void tsm::bneck_ws_kernel<64, true, false>(tsm::BneckParams)',
+               'void tsm::head_pool_kernel<2>(float const*)']
+
+    def counter_csv(d, counter, values):
+        os.makedirs(d)
+        with open(os.path.join(d, 'run_counter_collection.csv'), 'w') as f:
+            f.write('Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n')
+            disp = 1
+            for rep in range(3):           # three forwards: the tools take the last whole one
+                for k, v in zip(kernels, values):
+                    f.write(f'{disp},"{k}",{counter},{v}\n')
+                    disp += 1
+    frames, size = 256, 224
+    # KiB units; the read counter is doubled by the tool (gfx950 note)
+    counter_csv(str(tmp_path / 'f'), 'FETCH_SIZE', [400, 900, 1])
+    counter_csv(str(tmp_path / 'w'), 'WRITE_SIZE', [256, 4096, 1])
+    trace = tmp_path / 'trace.csv'
+    with open(trace, 'w') as f:
+        f.write('Kernel_Name,Start_Timestamp,End_Timestamp,Grid_Size_X,Workgroup_Size_X\n')
+        t = 0
+        for rep in range(3):
+            for k, us in zip(kernels, (500.0, 800.0, 1.0)):
+                f.write(f'"{k}",{t},{t + int(us * 1000)},256,256\n')
+                t += int(us * 1000) + 100
+    tpl.main(str(tmp_path / 'f'), str(tmp_path / 'w'), frames, size, 2, str(trace))
+    out = capsys.readouterr().out.splitlines()
+    head = out[0].split()
+    assert head[-4:] == ['us', 'bound_us', 'x_bound', 'roof']
+    from workoutdetector_amd.flops import layer_table
+    by = {r['name']: r for r in layer_table(size, size)}
+    row = next(l for l in out if l.startswith('layer1.0 (block)')).split()
+    us, bound, xb, roof = float(row[-4]), float(row[-3]), float(row[-2]), row[-1]
+    flops = 2.0 * frames * sum(by[q]['macs'] for q in ('layer1.0.conv1', 'layer1.0.conv2', 'layer1.0.conv3', 'layer1.0.downsample'))
+    hw = (size // 4) ** 2
+    # the block input for conv1 and once more for the downsample branch (the kernel does read it twice), the output, the four packed weight matrices
+    alg = frames * hw * (64 + 64 + 256) * 2 + (64 * 64 + 64 * 64 * 9 + 256 * 64 + 256 * 64) * 2
+    want = max(alg / 8.0e12, flops / 2.5e15) * 1e6
+    assert us == 800.0 and abs(bound - want) < 0.06 and abs(xb - 800.0 / want) < 0.01 and roof == ('hbm' if alg / 8.0e12 >= flops / 2.5e15 else 'mfma')
+    assert any(l.startswith('conv-like launches: 1300 us against') for l in out)
 
 
 def test_prefetch_pieces_covers_every_clip_once_and_survives_failures():
