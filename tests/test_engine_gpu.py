@@ -341,18 +341,20 @@ def test_split_k_is_bitwise_identical_to_whole_k(hip_lib, sd0, monkeypatch):
         assert np.array_equal(ref, outs[name]), name
 
 
-def test_tail_split_is_bitwise_identical_to_whole_k(hip_lib, sd0, monkeypatch):
+@pytest.mark.parametrize('clips', [14, 27])
+def test_tail_split_is_bitwise_identical_to_whole_k(hip_lib, sd0, monkeypatch, clips):
     """ConvParams::ksplit = 2 (tile code bit 0x200): the tiles of the last, partly filled round of resident workgroups of a
     segmented fp32 launch run as (tile, K segment) pieces + the ordered reduction over the tail rows only.  14 clips of
     224x224 put 1372 / 2744 tiles of 64x64 on the long-K layers of layer2-4 (rounds of 5 x 256 workgroups: the tail is 7-14 %
     of a round) and 688 on layer4's 3x3 (no whole round: the switch must fall back to the whole-K form there)."""
     from workoutdetector_amd.engine import TsmEngine, launch_trace
-    x = make_input(41, 14, 8, 224, 224)
+    # (27 clips: layer3's long-K launches are 2 646 tiles = 2.07 rounds -- a 7 % tail behind two whole rounds --, layer4's 1 323 = 1.03)
+    x = make_input(41, clips, 8, 224, 224)
     outs = {}
     for name, code in [('whole', 3), ('tail', 0x200 | 3)]:
         monkeypatch.setenv('TSM_AUTOTUNE', '1')
         monkeypatch.setenv('TSM_CONV_CODE', str(code))
-        eng = TsmEngine(height=224, width=224, max_clips=14, state_dict=sd0)
+        eng = TsmEngine(height=224, width=224, max_clips=clips, state_dict=sd0)
         outs[name] = eng.run(None, {'input': x})[0]
         with launch_trace() as tr:
             assert np.array_equal(eng.run(None, {'input': x})[0], outs[name])
@@ -361,7 +363,7 @@ def test_tail_split_is_bitwise_identical_to_whole_k(hip_lib, sd0, monkeypatch):
             if torch.cuda.get_device_properties(0).multi_processor_count == 256:
                 # layer3: 5 x conv1 (K = 1024) + 6 x conv2, layer4.0.conv1, layer4.0's conv3 + downsample GEMM, ... -- and NOT layer4's
                 # 3x3 / conv1 launches at 7x7 (688 tiles: no whole round), which keep the whole-K form
-                assert 10 <= n_reduce <= 16, (n_reduce, sorted(set(tr.kernels)))
+                assert 10 <= n_reduce <= 22, (n_reduce, sorted(set(tr.kernels)))
             else:
                 assert n_reduce >= 1, sorted(set(tr.kernels))
         else:
